@@ -1,0 +1,233 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's
+recognition forward (line batch -> conformer encoder -> linear decoder).
+
+Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import this module; the product path (conformer_ocr_amd/) never
+does and fails loudly without its HIP library.
+
+Written from the closed forms of SURVEY.md Appendix A, not from the reference's
+module code: native (B,H,W) input, channel-last activations, BatchNorm folded
+into the depthwise taps, the positional projection taken from the full
+9999-row table, integer length arithmetic.  Each function cites the reference
+file:line (relative to /root/reference/conformer_ocr) whose result it restates.
+
+Pinning: `tests/golden/make_golden.py` imports the reference encoder itself in
+the authoring container and stores its outputs (final and per stage) for the
+tiny / cfg1 configurations; `tests/test_oracle.py` checks this restatement
+against those fixtures (fp32: <= 2e-5 abs on logits).  The CTC decoders live in
+`ctc_ref.py` (third-party kraken algorithm: parity unpinned, see there).
+
+Everything takes and returns torch CPU tensors; `dtype` selects float32 (the
+reference's inference precision, cli/test.py:107) or float64.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-5
+BN_EPS = 1e-5
+POS_MAX_LEN = 5000
+
+
+def out_len(length, repeat: int = 2):
+    """calc_length, conformer/convolution.py:240-247 with k=3, s=2, p=1 (float math of the
+    reference reduces to (l-1)//2 + 1 per stage for integer l >= 1)."""
+    l = torch.as_tensor(length).to(torch.int64)
+    for _ in range(repeat):
+        l = torch.div(l - 1, 2, rounding_mode='floor') + 1
+    return l.to(torch.int32)
+
+
+def sinusoid_table(d_model: int, max_len: int = POS_MAX_LEN) -> torch.Tensor:
+    """conformer/embedding.py:35-56: rows 0..2*max_len-2 hold PE(p) for p = max_len-1 ... -(max_len-1);
+    PE(p)[2m] = sin(p w_m), PE(p)[2m+1] = cos(p w_m), w_m = exp(-2m ln(1e4)/d).  float32 like the reference."""
+    pos = torch.arange(max_len - 1, -max_len, -1, dtype=torch.float32).unsqueeze(1)      # +L-1 ... -(L-1)
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
+    pe = torch.zeros(2 * max_len - 1, d_model, dtype=torch.float32)
+    # the reference evaluates sin(-1 * position * div_term) for the negative half (embedding.py:49-50);
+    # (-p) * w == -(p * w) exactly in floating point, so one signed product restates both halves
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class Oracle:
+    """Functional forward over a plain state dict (keys `encoder.*`, `decoder.*`)."""
+
+    def __init__(self, hp, state: Mapping[str, np.ndarray], dtype=torch.float32):
+        self.hp = hp
+        self.dtype = dtype
+        self.w: Dict[str, torch.Tensor] = {}
+        for k, v in state.items():
+            t = torch.as_tensor(np.asarray(v))
+            self.w[k] = t.to(dtype) if t.is_floating_point() else t
+        self._pe = sinusoid_table(hp.encoder_dim).to(dtype)
+        self._ptab: Dict[int, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ frontend
+    def front_conv12(self, x_bhw: torch.Tensor) -> torch.Tensor:
+        """F1+F2 (convolution.py:192-205 applied to the (B,1,W,H) view of pred.py:119 / convolution.py:233).
+        Z1[b,c,t,f] = relu(b0[c] + sum w0[c,0,dt,df] X[b, 2f+df-1, 2t+dt-1]);
+        Z2[b,c,t,f] = b2[c] + sum w2[c,0,dt,df] Z1[b,c,2t+dt-1,2f+df-1].   Returns Z2 as (B,T,F,C)."""
+        w = self.w
+        x = x_bhw.to(self.dtype).transpose(1, 2).unsqueeze(1)                 # (B,1,W,H): conv rows run along image width
+        z1 = F.relu(F.conv2d(x, w['encoder.conv_subsample.conv.0.weight'], w['encoder.conv_subsample.conv.0.bias'],
+                             stride=2, padding=1))
+        C = z1.shape[1]
+        z2 = F.conv2d(z1, w['encoder.conv_subsample.conv.2.weight'], w['encoder.conv_subsample.conv.2.bias'],
+                      stride=2, padding=1, groups=C)
+        return z2.permute(0, 2, 3, 1).contiguous()                            # (B,T,F,C)
+
+    def front_pw(self, z2_btfc: torch.Tensor, idx: int = 3) -> torch.Tensor:
+        """F3 (convolution.py:207-213): Z3[b,t,f,o] = relu(b3[o] + sum_c w3[o,c] Z2[b,t,f,c])."""
+        w3 = self.w[f'encoder.conv_subsample.conv.{idx}.weight'].flatten(1)   # (C,C)
+        return F.relu(z2_btfc @ w3.t() + self.w[f'encoder.conv_subsample.conv.{idx}.bias'])
+
+    def front_dw(self, z_btfc: torch.Tensor, idx: int) -> torch.Tensor:
+        """extra stride-2 depthwise stage for subsampling_factor > 4 (convolution.py:200-205, loop body)."""
+        z = z_btfc.permute(0, 3, 1, 2)
+        C = z.shape[1]
+        z = F.conv2d(z, self.w[f'encoder.conv_subsample.conv.{idx}.weight'],
+                     self.w[f'encoder.conv_subsample.conv.{idx}.bias'], stride=2, padding=1, groups=C)
+        return z.permute(0, 2, 3, 1).contiguous()
+
+    def front_out(self, z3_btfc: torch.Tensor) -> torch.Tensor:
+        """F4+F5 (convolution.py:224,235-236): Y[b,t,:] = Wout vec_{c,f}(Z3[b,:,t,:]) + bout, vec index c*F+f."""
+        B, T, Fh, C = z3_btfc.shape
+        v = z3_btfc.permute(0, 1, 3, 2).reshape(B, T, C * Fh)
+        return v @ self.w['encoder.conv_subsample.out.0.weight'].t() + self.w['encoder.conv_subsample.out.0.bias']
+
+    def frontend(self, x_bhw: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        if self.hp.sampling_num == 1:
+            # factor 2: conv.0 + ReLU only
+            w = self.w
+            x = x_bhw.to(self.dtype).transpose(1, 2).unsqueeze(1)
+            z = F.relu(F.conv2d(x, w['encoder.conv_subsample.conv.0.weight'], w['encoder.conv_subsample.conv.0.bias'],
+                                stride=2, padding=1)).permute(0, 2, 3, 1).contiguous()
+        else:
+            z2 = self.front_conv12(x_bhw)
+            z = self.front_pw(z2, 3)
+            if taps is not None:
+                taps['front.z2'] = z2
+                taps['front.z3'] = z
+            idx = 5
+            for _ in range(self.hp.sampling_num - 2):
+                z = self.front_pw(self.front_dw(z, idx), idx + 1)
+                idx += 3
+        y = self.front_out(z)
+        if taps is not None:
+            taps['front.y'] = y
+        return y
+
+    # ------------------------------------------------------------------ block parts
+    def _ln(self, x: torch.Tensor, prefix: str) -> torch.Tensor:
+        return F.layer_norm(x, (x.shape[-1],), self.w[prefix + '.weight'], self.w[prefix + '.bias'], LN_EPS)
+
+    def ffn(self, y: torch.Tensor, l: int, which: int) -> torch.Tensor:
+        """feed_forward.py:45-52 inside ResidualConnectionModule (modules.py:32, encoder.py:62-75):
+        y + f * (W2 silu(W1 LN(y) + b1) + b2), f = 0.5 with half_step_residual."""
+        p = f'encoder.layers.{l}.sequential.{which}.module.sequential.'
+        t = self._ln(y, p + '0')
+        t = F.silu(t @ self.w[p + '1.linear.weight'].t() + self.w[p + '1.linear.bias'])
+        t = t @ self.w[p + '4.linear.weight'].t() + self.w[p + '4.linear.bias']
+        return y + self.hp.ff_residual_factor * t
+
+    def pos_table(self, l: int) -> torch.Tensor:
+        """P_full = PE_full Wpos^T (attention.py:62,85 on embedding.py:66's table), 9999 x D; row 4999 <-> p = 0."""
+        if l not in self._ptab:      # input-independent: computed once per layer, like a load-time constant
+            p = f'encoder.layers.{l}.sequential.1.module.attention.'
+            self._ptab[l] = self._pe @ self.w[p + 'pos_proj.linear.weight'].t()
+        return self._ptab[l]
+
+    def mhsa(self, y: torch.Tensor, l: int, taps: Optional[dict] = None) -> torch.Tensor:
+        """attention.py:72-103,143-151:
+        score[b,h,i,j] = ((q_i+u_h).k_j + (q_i+v_h).P_h[(T-1)-(i-j)]) / sqrt(dh), softmax over ALL j (no mask)."""
+        hp = self.hp
+        B, T, D = y.shape
+        h, dh = hp.num_attention_heads, hp.d_head
+        m = f'encoder.layers.{l}.sequential.1.module.'
+        a = m + 'attention.'
+        xn = self._ln(y, m + 'layer_norm')
+        q = (xn @ self.w[a + 'query_proj.linear.weight'].t() + self.w[a + 'query_proj.linear.bias']).view(B, T, h, dh)
+        k = (xn @ self.w[a + 'key_proj.linear.weight'].t() + self.w[a + 'key_proj.linear.bias']).view(B, T, h, dh)
+        v = (xn @ self.w[a + 'value_proj.linear.weight'].t() + self.w[a + 'value_proj.linear.bias']).view(B, T, h, dh)
+        P = self.pos_table(l).view(-1, h, dh)                                  # (9999,h,dh)
+        cen = POS_MAX_LEN - 1
+        i = torch.arange(T).view(T, 1)
+        j = torch.arange(T).view(1, T)
+        rel = cen - (i - j)                                                    # row index of P for (i,j)
+        qu = (q + self.w[a + 'u_bias']).permute(0, 2, 1, 3)                     # (B,h,T,dh)
+        qv = (q + self.w[a + 'v_bias']).permute(0, 2, 1, 3)
+        content = qu @ k.permute(0, 2, 3, 1)                                    # (B,h,T,T)
+        Pband = P[cen - (T - 1): cen + T]                                      # (2T-1,h,dh): p = T-1 ... -(T-1)
+        pos_all = qv @ Pband.permute(1, 2, 0)                                   # (B,h,T,2T-1)
+        pos = torch.gather(pos_all, 3, (rel - (cen - (T - 1))).expand(B, h, T, T))
+        score = (content + pos) / math.sqrt(dh)
+        attn = torch.softmax(score, -1)
+        ctx = (attn @ v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, T, D)
+        out = ctx @ self.w[a + 'out_proj.linear.weight'].t() + self.w[a + 'out_proj.linear.bias']
+        if taps is not None:
+            taps[f'l{l}.q'] = q
+            taps[f'l{l}.k'] = k
+            taps[f'l{l}.v'] = v
+            taps[f'l{l}.ctx'] = ctx
+        return y + out
+
+    def convmod(self, y: torch.Tensor, l: int, taps: Optional[dict] = None) -> torch.Tensor:
+        """convolution.py:135-148 (SURVEY A.1b CONV): LN -> PW(D->2D) -> GLU -> depthwise k (zero pad at the
+        PADDED batch edges) -> BatchNorm(eval, folded) -> SiLU -> PW(D->D); residual x1 (modules.py:32)."""
+        hp = self.hp
+        B, T, D = y.shape
+        k = hp.conv_kernel_size
+        c = f'encoder.layers.{l}.sequential.2.module.sequential.'
+        t = self._ln(y, c + '0')
+        a = t @ self.w[c + '2.conv.weight'].squeeze(-1).t() + self.w[c + '2.conv.bias']   # (B,T,2D)
+        g = a[..., :D] * torch.sigmoid(a[..., D:])
+        s = self.w[c + '5.weight'] / torch.sqrt(self.w[c + '5.running_var'] + BN_EPS)
+        wdw = self.w[c + '4.conv.weight'].squeeze(1) * s.unsqueeze(1)          # (D,k) folded taps
+        bdw = self.w[c + '5.bias'] - self.w[c + '5.running_mean'] * s
+        gp = F.pad(g, (0, 0, (k - 1) // 2, (k - 1) // 2))                      # zero rows before/after time
+        u = bdw + sum(gp[:, tau:tau + T, :] * wdw[:, tau] for tau in range(k))
+        u = F.silu(u)
+        out = u @ self.w[c + '7.conv.weight'].squeeze(-1).t() + self.w[c + '7.conv.bias']
+        if taps is not None:
+            taps[f'l{l}.glu'] = g
+            taps[f'l{l}.dw'] = u
+        return y + out
+
+    def block(self, y: torch.Tensor, l: int, taps: Optional[dict] = None) -> torch.Tensor:
+        """encoder.py:67-100: FFN(half) -> MHSA -> Conv -> FFN(half) -> LayerNorm."""
+        y = self.ffn(y, l, 0)
+        if taps is not None:
+            taps[f'l{l}.ffn1'] = y
+        y = self.mhsa(y, l, taps)
+        if taps is not None:
+            taps[f'l{l}.mhsa'] = y
+        y = self.convmod(y, l, taps)
+        if taps is not None:
+            taps[f'l{l}.conv'] = y
+        y = self.ffn(y, l, 3)
+        if taps is not None:
+            taps[f'l{l}.ffn2'] = y
+        y = self._ln(y, f'encoder.layers.{l}.sequential.4')
+        if taps is not None:
+            taps[f'l{l}.out'] = y
+        return y
+
+    # ------------------------------------------------------------------ whole path
+    @torch.no_grad()
+    def forward(self, line: torch.Tensor, lens, taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """PytorchRecognitionModel.forward (pred.py:118-122): line (N,1,H,W) -> (probits (N,T,ncls), lens int32).
+        NO masking anywhere: the padded region takes part."""
+        x = line.squeeze(1)                                                    # (N,H,W); the reference's transpose is a view
+        y = self.frontend(x, taps)
+        for l in range(self.hp.num_encoder_layers):
+            y = self.block(y, l, taps)
+        logits = y @ self.w['decoder.weight'].t() + self.w['decoder.bias']
+        return logits, out_len(lens, self.hp.sampling_num)

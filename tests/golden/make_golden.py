@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""
+Generates the golden fixtures in this directory by running THE REFERENCE ITSELF
+(`/root/reference/conformer_ocr/conformer/encoder.py::ConformerEncoder`, torch
+CPU fp32, eval mode) on seeded synthetic weights and line batches.
+
+Run in the authoring container only (the reference does not travel to the GPU
+box):   python tests/golden/make_golden.py
+
+What is stored is data only: inputs are regenerated from seeds by
+`conformer_ocr_amd.synth`, expected outputs (logits, per-stage activations,
+lengths, state-dict key list) are stored as .npz.  `conformer_ocr.pred` /
+`.model` are not importable (SyntaxError at pred.py:213-217; lightning/kraken
+absent), so the 3 lines of `PytorchRecognitionModel.forward` (pred.py:119-121:
+squeeze/transpose, encoder, `nn.Linear` decoder) are applied here around the
+imported encoder.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+from conformer_ocr.conformer.encoder import ConformerEncoder  # noqa: E402  (the reference)
+
+from conformer_ocr_amd import synth  # noqa: E402
+from conformer_ocr_amd.spec import HParams  # noqa: E402
+
+
+def build_reference(hp: HParams, state):
+    enc = ConformerEncoder(in_channels=1, input_dim=hp.height, encoder_dim=hp.encoder_dim,
+                           num_layers=hp.num_encoder_layers, num_attention_heads=hp.num_attention_heads,
+                           feed_forward_expansion_factor=hp.feed_forward_expansion_factor,
+                           conv_expansion_factor=hp.conv_expansion_factor,
+                           conv_kernel_size=hp.conv_kernel_size, half_step_residual=hp.half_step_residual,
+                           subsampling_conv_channels=hp.subsampling_conv_channels,
+                           subsampling_factor=hp.subsampling_factor)
+    dec = torch.nn.Linear(hp.encoder_dim, hp.num_classes, bias=True)                 # pred.py:90
+    enc_sd = {k[len('encoder.'):]: torch.from_numpy(np.asarray(v)) for k, v in state.items() if k.startswith('encoder.')}
+    missing = enc.load_state_dict(enc_sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    dec.load_state_dict({'weight': torch.from_numpy(state['decoder.weight']), 'bias': torch.from_numpy(state['decoder.bias'])})
+    return enc.eval(), dec.eval()
+
+
+def reference_forward(enc, dec, image, lens, taps=None):
+    """pred.py:118-122 around the reference encoder; optional forward hooks collect stage outputs."""
+    hooks = []
+    if taps is not None:
+        def tap(name, fn=lambda t: t):
+            def hook(_m, _i, o):
+                taps[name] = fn(o.detach().clone())
+            return hook
+        cs = enc.conv_subsample
+        hooks.append(cs.conv[2].register_forward_hook(tap('front.z2', lambda t: t.permute(0, 2, 3, 1))))   # (B,C,T,F)->(B,T,F,C)
+        hooks.append(cs.conv[4].register_forward_hook(tap('front.z3', lambda t: t.permute(0, 2, 3, 1))))
+        hooks.append(cs.out.register_forward_hook(tap('front.y')))
+        for l, layer in enumerate(enc.layers):
+            for i, nm in enumerate(('ffn1', 'mhsa', 'conv', 'ffn2', 'out')):
+                hooks.append(layer.sequential[i].register_forward_hook(tap(f'l{l}.{nm}')))
+    with torch.no_grad():
+        line = torch.from_numpy(image).squeeze(1).transpose(1, 2)                   # pred.py:119
+        eo, el = enc(line, torch.from_numpy(lens))                                  # pred.py:120
+        logits = dec(eo)                                                            # pred.py:121
+    for h in hooks:
+        h.remove()
+    return logits.numpy(), el.numpy()
+
+
+def calibrate_decoder_bias(enc, state, image, lens, blank_share=0.35):
+    """With random weights every frame decodes to the same label (the frame-independent part of the
+    encoder output dominates).  Centre the decoder on the reference's own mean encoder output and
+    lift the blank so that it wins about `blank_share` of the frames: greedy strings then have
+    runs, repeats and blanks.  The resulting bias vector is stored in the fixture."""
+    with torch.no_grad():
+        eo, _ = enc(torch.from_numpy(image).squeeze(1).transpose(1, 2), torch.from_numpy(lens))
+    w = torch.from_numpy(state['decoder.weight'])
+    mu = eo.reshape(-1, eo.shape[-1]).mean(0)
+    bias = -(w @ mu)
+    lg = eo @ w.t() + bias
+    gap = (lg[..., 1:].max(-1).values - lg[..., 0]).flatten()
+    bias[0] += torch.quantile(gap, blank_share)
+    return bias.numpy().astype(np.float32)
+
+
+def margins(logits):
+    srt = np.sort(logits, axis=-1)
+    return (srt[..., -1] - srt[..., -2]).astype(np.float32)
+
+
+def run_case(meta, name, hp, seed, n, W, widths=None, with_taps=False, head=None, gain=8.0,
+             line_seed=None, reuse=None):
+    """One fixture: seeded weights (+ calibrated decoder bias) and lines -> reference outputs."""
+    line_seed = seed if line_seed is None else line_seed
+    image, lens = synth.make_lines(n, hp.height, W, seed=line_seed, widths=widths)
+    if reuse is None:
+        state = synth.make_state_dict(hp, seed=seed, decoder_gain=gain)
+        enc, _ = build_reference(hp, state)
+        state['decoder.bias'] = calibrate_decoder_bias(enc, state, image, lens)
+        enc, dec = build_reference(hp, state)
+    else:
+        state, enc, dec = reuse
+    taps = {} if with_taps else None
+    logits, olens = reference_forward(enc, dec, image, lens, taps)
+    out = {'out_lens': olens, 'decoder_bias': state['decoder.bias'],
+           'labels': np.argmax(logits, -1).astype(np.int16), 'margins': margins(logits).astype(np.float16)}
+    if head is None:
+        out['logits'] = logits
+    else:
+        out['logits_head'] = logits[:head]
+    if with_taps:
+        for k, v in taps.items():
+            out['tap:' + k] = v.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    lab = out['labels']
+    meta[name] = {'hparams': hp.as_dict(), 'seed': seed, 'line_seed': line_seed, 'decoder_gain': gain, 'N': n, 'W': W,
+                  'widths': [int(x) for x in lens], 'sha256_logits': hashlib.sha256(logits.tobytes()).hexdigest(),
+                  'distinct_labels': int(len(np.unique(lab))), 'blank_share': float((lab == 0).mean()),
+                  'margin_q01': float(np.quantile(margins(logits), 0.01))}
+    print(name, {k: meta[name][k] for k in ('distinct_labels', 'blank_share', 'margin_q01')})
+    return state, enc, dec
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    meta = {}
+    # tiny: full per-stage taps, padding leak exercised (widths 64/37/50 padded to 64)
+    hp = synth.hparams('tiny')
+    _, enc, _ = run_case(meta, 'tiny', hp, 1234, 3, 64, widths=[64, 37, 50], with_taps=True)
+    meta['tiny']['encoder_state_keys'] = [(k, list(v.shape), str(v.dtype)) for k, v in enc.state_dict().items()]
+    # tiny8: subsampling_factor 8 (extra depthwise/pointwise stage)
+    hp8 = synth.hparams('tiny', subsampling_factor=8, height=32)
+    _, enc8, _ = run_case(meta, 'tiny8', hp8, 1235, 2, 96, widths=[96, 61])
+    meta['tiny8']['encoder_state_keys'] = [(k, list(v.shape), str(v.dtype)) for k, v in enc8.state_dict().items()]
+    # cfg1: default_specs.py verbatim, BASELINE configs[0]: 4 lines 96x512 (lens 512,400,300,512)
+    hp1 = synth.hparams('cfg1')
+    _, enc1, _ = run_case(meta, 'cfg1', hp1, 1235, 4, 512, widths=[512, 400, 300, 512])
+    meta['cfg1']['n_params_encoder'] = int(sum(p.numel() for p in enc1.parameters()))
+    # cfg2: the metric's configuration (D=256, L=12, h=4, C=256), batch 32 x 96x1200:
+    # full logits of lines 0..3, argmax labels + top-2 margins of all 32 lines
+    hp2 = synth.hparams('cfg2')
+    reuse = run_case(meta, 'cfg2', hp2, 1236, 32, 1200, head=4)
+    # cfg2 ragged: 6 lines of mixed widths right-padded to 1200 (padding-leak case at full size), same weights
+    run_case(meta, 'cfg2_ragged', hp2, 1236, 6, 1200, widths=[1200, 1111, 903, 640, 417, 1200], head=2,
+             line_seed=1237, reuse=reuse)
+    # cfg4 (wide conformer D=512, L=16, h=8): 3 lines of bucketed widths padded to 1400
+    hp4 = synth.hparams('cfg4')
+    run_case(meta, 'cfg4', hp4, 1238, 3, 1400, widths=[1400, 1256, 1208], head=1)
+    with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
+        json.dump(meta, fp, indent=1)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == '__main__':
+    main()
