@@ -1,0 +1,50 @@
+"""Builds libcocr_hip.so (the gfx950 kernels + C ABI) in-tree with hipcc.
+
+    python -m conformer_ocr_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels with the tree."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+LIB_DIR = os.path.join(PKG, 'lib')
+LIB = os.path.join(LIB_DIR, 'libcocr_hip.so')
+INCLUDE = os.path.join(os.path.dirname(PKG), 'include')
+ARCH = 'gfx950'
+
+
+def sources():
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    return srcs + [os.path.join(INCLUDE, 'cocr.h')]
+
+
+def up_to_date() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(s) <= t for s in sources())
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and up_to_date():
+        return LIB
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        raise RuntimeError('hipcc not found: cannot build libcocr_hip.so')
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-fgpu-rdc' if False else '-fno-gpu-rdc',
+           '-Wall', '-Wno-unused-function', '-I', INCLUDE, os.path.join(CSRC, 'cocr_api.hip'), '-o', LIB + '.tmp']
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(LIB + '.tmp', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

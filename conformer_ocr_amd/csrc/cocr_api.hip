@@ -1,0 +1,787 @@
+// libcocr_hip.so -- C ABI (include/cocr.h) and host orchestration of the gfx950 kernels.
+//
+// A model is: the reference state dict (fp32, host) -> one packed device blob in the compute dtype
+// (cocr_finalize) -> a workspace sized for (N, W) -> a fixed sequence of kernel launches on the
+// caller's stream (cocr_forward).  Nothing here falls back to the CPU: without a GPU every compute
+// entry point fails with COCR_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cocr.h"
+#include "attention.hip.h"
+#include "common.hip.h"
+#include "conv.hip.h"
+#include "ctc.hip.h"
+#include "gemm.hip.h"
+#include "norm.hip.h"
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(COCR_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *cocr_last_error(void) { return g_err; }
+extern "C" const char *cocr_version(void) { return "cocr-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------ model
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    bool set = false;
+};
+
+struct FfnW { size_t ln_g, ln_b, w1, b1, w2, b2; };
+struct LayerW {
+    FfnW ffn[2];
+    size_t a_ln_g, a_ln_b, wqkv, bqkv, ub, vb, ptab, wo, bo;
+    size_t c_ln_g, c_ln_b, wpw1, bpw1, dww, dwb, wpw2, bpw2;
+    size_t f_ln_g, f_ln_b;
+};
+struct StageW { size_t dw_w, dw_b, pw_w, pw_b; };   // one (depthwise, pointwise) frontend stage
+struct BlobPlan {
+    size_t w0, b0;                 // frontend conv.0 taps [C][9], bias
+    std::vector<StageW> stages;    // sampling_num - 1 stages; stage 0's depthwise is fused with conv.0
+    size_t wout, bout;
+    std::vector<LayerW> layers;
+    size_t wdec, bdec;
+    size_t total = 0;
+};
+
+struct DevBuf { void *p = nullptr; size_t bytes = 0; };
+
+struct ProfRec { int fam; hipEvent_t a, b; };
+
+struct cocr_model {
+    cocr_hparams hp;
+    int device = 0;
+    // derived
+    int D, C, L, heads, dh, dhp, ff, ksz, ncls, H, snum;
+    std::vector<int> feats;   // height after each stride-2 stage: feats[0] = F1, ...
+    std::map<std::string, HostTensor> host;
+    std::vector<std::string> names;
+    // packed weights
+    int dtype = -1;
+    unsigned char *blob = nullptr;
+    BlobPlan plan;
+    // workspace
+    int capN = 0, capW = 0;
+    std::vector<void *> ws_allocs;
+    void *z_a = nullptr, *z_b = nullptr;
+    float *x = nullptr;
+    void *xn = nullptr, *hid = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *glu = nullptr, *dwo = nullptr;
+    size_t qkv_bytes = 0;
+    int vtN = -1, vtT = -1;    // shape the q/k/vt buffers were last zeroed for
+    int32_t *d_lens = nullptr;
+    int32_t *ctc_lab = nullptr;
+    float *ctc_val = nullptr;
+    size_t ctc_cap = 0;
+    int lens_cap = 0;
+    // debug / profile
+    bool debug = false;
+    std::map<std::string, std::pair<float *, int64_t>> taps;
+    bool profile = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static const char *FAMILIES[] = {"frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
+                                 "gemm_ffn_up", "gemm_ffn_down", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
+                                 "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam"};
+enum { FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
+       FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_COUNT };
+
+static int out_len1(int l) { return l >= 1 ? (l - 1) / 2 + 1 : 0; }
+
+extern "C" int32_t cocr_out_len(int32_t in_len, int32_t subsampling_factor) {
+    int n = 0;
+    for (int f = subsampling_factor; f > 1; f >>= 1) ++n;
+    for (int i = 0; i < n; ++i) in_len = out_len1(in_len);
+    return in_len;
+}
+
+static void add_name(cocr_model *m, const std::string &n) { m->names.push_back(n); m->host[n]; }
+
+extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out) {
+    if (!hp || !out) return fail(COCR_EINVAL, "null argument");
+    if (hp->num_classes < 1 || hp->height < 1 || hp->encoder_dim < 1 || hp->num_encoder_layers < 1 || hp->num_attention_heads < 1)
+        return fail(COCR_EINVAL, "non-positive hyper-parameter");
+    if (hp->encoder_dim % hp->num_attention_heads) return fail(COCR_EINVAL, "d_model %% num_heads should be zero.");
+    if ((hp->conv_kernel_size - 1) % 2 || hp->conv_kernel_size < 1) return fail(COCR_EINVAL, "kernel_size should be a odd number for 'SAME' padding");
+    if (hp->conv_expansion_factor != 2) return fail(COCR_EINVAL, "Currently, Only Supports expansion_factor 2");
+    int sf = hp->subsampling_factor, snum = 0;
+    if (sf < 2 || (sf & (sf - 1))) return fail(COCR_EINVAL, "Sampling factor should be a power of 2.");
+    for (int f = sf; f > 1; f >>= 1) ++snum;
+    if (snum < 2) return fail(COCR_EUNSUPPORTED, "subsampling_factor 2 is not covered by the fused frontend kernel");
+    if (hp->encoder_dim % 16) return fail(COCR_EUNSUPPORTED, "encoder_dim must be a multiple of 16 (GLU tile pairing, 16-byte rows)");
+    if (hp->subsampling_conv_channels % 8) return fail(COCR_EUNSUPPORTED, "subsampling_conv_channels must be a multiple of 8");
+    if (hp->encoder_dim > 64 * COCR_LN_MAX_PER_LANE) return fail(COCR_EUNSUPPORTED, "encoder_dim > 1024");
+    const int dh = hp->encoder_dim / hp->num_attention_heads;
+    if (dh > 128) return fail(COCR_EUNSUPPORTED, "d_head > 128");
+    cocr_model *m = new cocr_model();
+    m->hp = *hp;
+    m->device = device;
+    m->D = hp->encoder_dim; m->C = hp->subsampling_conv_channels; m->L = hp->num_encoder_layers;
+    m->heads = hp->num_attention_heads; m->dh = dh; m->dhp = round_up(dh, 32);
+    m->ff = hp->feed_forward_expansion_factor * hp->encoder_dim; m->ksz = hp->conv_kernel_size;
+    m->ncls = hp->num_classes; m->H = hp->height; m->snum = snum;
+    int f = hp->height;
+    for (int i = 0; i < snum; ++i) { f = out_len1(f); m->feats.push_back(f); }
+    // expected state-dict entries, reference key names
+    char buf[256];
+    add_name(m, "encoder.conv_subsample.conv.0.weight");
+    add_name(m, "encoder.conv_subsample.conv.0.bias");
+    for (int s = 0, idx = 2; s < snum - 1; ++s, idx += 3) {
+        for (int j = 0; j < 2; ++j) {
+            snprintf(buf, sizeof buf, "encoder.conv_subsample.conv.%d.weight", idx + j); add_name(m, buf);
+            snprintf(buf, sizeof buf, "encoder.conv_subsample.conv.%d.bias", idx + j); add_name(m, buf);
+        }
+    }
+    add_name(m, "encoder.conv_subsample.out.0.weight");
+    add_name(m, "encoder.conv_subsample.out.0.bias");
+    for (int l = 0; l < m->L; ++l) {
+        auto nm = [&](const char *suffix) { snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.%s", l, suffix); add_name(m, buf); };
+        for (int w = 0; w < 2; ++w) {
+            const char *pre = w == 0 ? "0" : "3";
+            for (const char *s : {"module.sequential.0.weight", "module.sequential.0.bias", "module.sequential.1.linear.weight",
+                                  "module.sequential.1.linear.bias", "module.sequential.4.linear.weight", "module.sequential.4.linear.bias"}) {
+                char b2[200]; snprintf(b2, sizeof b2, "%s.%s", pre, s); nm(b2);
+            }
+        }
+        for (const char *s : {"1.module.layer_norm.weight", "1.module.layer_norm.bias", "1.module.attention.u_bias", "1.module.attention.v_bias",
+                              "1.module.attention.query_proj.linear.weight", "1.module.attention.query_proj.linear.bias",
+                              "1.module.attention.key_proj.linear.weight", "1.module.attention.key_proj.linear.bias",
+                              "1.module.attention.value_proj.linear.weight", "1.module.attention.value_proj.linear.bias",
+                              "1.module.attention.pos_proj.linear.weight", "1.module.attention.out_proj.linear.weight",
+                              "1.module.attention.out_proj.linear.bias",
+                              "2.module.sequential.0.weight", "2.module.sequential.0.bias", "2.module.sequential.2.conv.weight",
+                              "2.module.sequential.2.conv.bias", "2.module.sequential.4.conv.weight", "2.module.sequential.5.weight",
+                              "2.module.sequential.5.bias", "2.module.sequential.5.running_mean", "2.module.sequential.5.running_var",
+                              "2.module.sequential.7.conv.weight", "2.module.sequential.7.conv.bias", "4.weight", "4.bias"})
+            nm(s);
+    }
+    add_name(m, "decoder.weight");
+    add_name(m, "decoder.bias");
+    *out = m;
+    return COCR_OK;
+}
+
+static void free_workspace(cocr_model *m) {
+    for (void *p : m->ws_allocs) (void)hipFree(p);
+    m->ws_allocs.clear();
+    m->capN = m->capW = 0;
+    m->vtN = m->vtT = -1;
+}
+static void clear_taps(cocr_model *m) {
+    for (auto &kv : m->taps) (void)hipFree(kv.second.first);
+    m->taps.clear();
+}
+
+extern "C" void cocr_destroy(cocr_model *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    free_workspace(m);
+    clear_taps(m);
+    if (m->blob) (void)hipFree(m->blob);
+    if (m->d_lens) (void)hipFree(m->d_lens);
+    if (m->ctc_lab) (void)hipFree(m->ctc_lab);
+    if (m->ctc_val) (void)hipFree(m->ctc_val);
+    for (auto &r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : m->ev_pool) (void)hipEventDestroy(e);
+    delete m;
+}
+
+extern "C" int cocr_set_tensor(cocr_model *m, const char *name, const void *host, int dtype, int ndim, const int64_t *shape) {
+    if (!m || !name || !host) return fail(COCR_EINVAL, "null argument");
+    std::string n(name);
+    if (n.size() > 20 && n.compare(n.size() - 19, 19, "num_batches_tracked") == 0) return COCR_OK;   // BatchNorm counter: unused in eval
+    auto it = m->host.find(n);
+    if (it == m->host.end()) return fail(COCR_EINVAL, "unexpected key '%s'", name);
+    if (dtype != COCR_F32) return fail(COCR_EINVAL, "tensor '%s': only float32 state is accepted", name);
+    int64_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) cnt *= shape[i];
+    it->second.shape.assign(shape, shape + ndim);
+    it->second.data.assign((const float *)host, (const float *)host + cnt);
+    it->second.set = true;
+    return COCR_OK;
+}
+
+extern "C" int cocr_missing_tensors(cocr_model *m, char *buf, size_t buflen) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    int cnt = 0;
+    std::string s;
+    for (auto &n : m->names)
+        if (!m->host[n].set) { ++cnt; s += n; s += '\n'; }
+    if (buf && buflen) { strncpy(buf, s.c_str(), buflen - 1); buf[buflen - 1] = 0; }
+    return cnt;
+}
+
+// ------------------------------------------------------------------------------------ blob
+static size_t esize(int dtype) { return dtype == COCR_BF16 ? 2 : 4; }
+
+static BlobPlan make_plan(const cocr_model *m, int dtype) {
+    BlobPlan p;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t es = esize(dtype);
+    const int D = m->D, C = m->C, ff = m->ff;
+    p.w0 = take((size_t)C * 9 * 4); p.b0 = take((size_t)C * 4);
+    for (int s = 0; s < m->snum - 1; ++s) {
+        StageW st;
+        st.dw_w = take((size_t)C * 9 * 4); st.dw_b = take((size_t)C * 4);
+        st.pw_w = take((size_t)C * C * es); st.pw_b = take((size_t)C * 4);
+        p.stages.push_back(st);
+    }
+    const int F = m->feats.back();
+    p.wout = take((size_t)D * F * C * es); p.bout = take((size_t)D * 4);
+    for (int l = 0; l < m->L; ++l) {
+        LayerW w;
+        for (int i = 0; i < 2; ++i) {
+            w.ffn[i].ln_g = take(D * 4); w.ffn[i].ln_b = take(D * 4);
+            w.ffn[i].w1 = take((size_t)ff * D * es); w.ffn[i].b1 = take((size_t)ff * 4);
+            w.ffn[i].w2 = take((size_t)D * ff * es); w.ffn[i].b2 = take(D * 4);
+        }
+        w.a_ln_g = take(D * 4); w.a_ln_b = take(D * 4);
+        w.wqkv = take((size_t)3 * D * D * es); w.bqkv = take((size_t)3 * D * 4);
+        w.ub = take(D * 4); w.vb = take(D * 4);
+        w.ptab = take((size_t)COCR_POS_ROWS * m->heads * m->dhp * es);
+        w.wo = take((size_t)D * D * es); w.bo = take(D * 4);
+        w.c_ln_g = take(D * 4); w.c_ln_b = take(D * 4);
+        w.wpw1 = take((size_t)2 * D * D * es); w.bpw1 = take((size_t)2 * D * 4);
+        w.dww = take((size_t)m->ksz * D * 4); w.dwb = take(D * 4);
+        w.wpw2 = take((size_t)D * D * es); w.bpw2 = take(D * 4);
+        w.f_ln_g = take(D * 4); w.f_ln_b = take(D * 4);
+        p.layers.push_back(w);
+    }
+    p.wdec = take((size_t)m->ncls * D * es); p.bdec = take((size_t)m->ncls * 4);
+    p.total = off;
+    return p;
+}
+
+static uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// writes rows x cols of src (row i taken from src row map(i)) as compute dtype
+static void put_matrix(unsigned char *dst, int dtype, const float *src, int rows, int cols, const std::vector<int> *rowmap = nullptr,
+                       const std::vector<int> *colmap = nullptr) {
+    for (int r = 0; r < rows; ++r) {
+        const float *s = src + (size_t)(rowmap ? (*rowmap)[r] : r) * cols;
+        for (int c = 0; c < cols; ++c) {
+            const float v = s[colmap ? (*colmap)[c] : c];
+            if (dtype == COCR_BF16) ((uint16_t *)dst)[(size_t)r * cols + c] = f32_to_bf16(v);
+            else ((float *)dst)[(size_t)r * cols + c] = v;
+        }
+    }
+}
+static void put_f32(unsigned char *dst, const float *src, size_t n) { memcpy(dst, src, n * 4); }
+
+static int expect_shape(const cocr_model *m, const std::string &name, std::initializer_list<int64_t> shape, const HostTensor **out) {
+    auto it = m->host.find(name);
+    if (it == m->host.end() || !it->second.set) return fail(COCR_ESTATE, "missing tensor '%s'", name.c_str());
+    if (it->second.shape != std::vector<int64_t>(shape)) {
+        std::string got;
+        for (auto v : it->second.shape) got += std::to_string(v) + ",";
+        return fail(COCR_EINVAL, "size mismatch for %s: got (%s)", name.c_str(), got.c_str());
+    }
+    *out = &it->second;
+    return COCR_OK;
+}
+
+template <typename T> static int compute_pos_tables(cocr_model *m, const std::vector<const HostTensor *> &wpos);
+
+static int alloc_blob(cocr_model *m, int dtype) {
+    if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
+    m->plan = make_plan(m, dtype);
+    m->dtype = dtype;
+    HIP_TRY(hipMalloc((void **)&m->blob, m->plan.total));
+    HIP_TRY(hipMemset(m->blob, 0, m->plan.total));
+    return COCR_OK;
+}
+
+extern "C" int cocr_finalize_empty(cocr_model *m, int compute_dtype) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    int rc = alloc_blob(m, compute_dtype);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return COCR_OK;
+}
+
+extern "C" int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes) {
+    if (!m || !device_ptr || !bytes) return fail(COCR_EINVAL, "null argument");
+    if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
+    *device_ptr = m->blob;
+    *bytes = m->plan.total;
+    return COCR_OK;
+}
+
+extern "C" int cocr_finalize(cocr_model *m, int dtype) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");
+    const int D = m->D, C = m->C, ff = m->ff, k = m->ksz, h = m->heads, dh = m->dh;
+    const BlobPlan plan = make_plan(m, dtype);
+    std::vector<unsigned char> stage(plan.total, 0);
+    unsigned char *st = stage.data();
+    const HostTensor *t = nullptr;
+    int rc;
+    char buf[256];
+#define GET(NAME, ...)                                          \
+    if ((rc = expect_shape(m, NAME, {__VA_ARGS__}, &t))) return rc;
+    GET("encoder.conv_subsample.conv.0.weight", C, 1, 3, 3); put_f32(st + plan.w0, t->data.data(), (size_t)C * 9);
+    GET("encoder.conv_subsample.conv.0.bias", C); put_f32(st + plan.b0, t->data.data(), C);
+    for (int s = 0, idx = 2; s < m->snum - 1; ++s, idx += 3) {
+        snprintf(buf, sizeof buf, "encoder.conv_subsample.conv.%d.weight", idx); GET(buf, C, 1, 3, 3); put_f32(st + plan.stages[s].dw_w, t->data.data(), (size_t)C * 9);
+        snprintf(buf, sizeof buf, "encoder.conv_subsample.conv.%d.bias", idx); GET(buf, C); put_f32(st + plan.stages[s].dw_b, t->data.data(), C);
+        snprintf(buf, sizeof buf, "encoder.conv_subsample.conv.%d.weight", idx + 1); GET(buf, C, C, 1, 1); put_matrix(st + plan.stages[s].pw_w, dtype, t->data.data(), C, C);
+        snprintf(buf, sizeof buf, "encoder.conv_subsample.conv.%d.bias", idx + 1); GET(buf, C); put_f32(st + plan.stages[s].pw_b, t->data.data(), C);
+    }
+    {   // flatten order: the reference's feature index is c*F + f (convolution.py:235-236); ours is f*C + c
+        const int F = m->feats.back();
+        GET("encoder.conv_subsample.out.0.weight", D, (int64_t)C * F);
+        std::vector<int> colmap((size_t)F * C);
+        for (int f = 0; f < F; ++f) for (int c = 0; c < C; ++c) colmap[(size_t)f * C + c] = c * F + f;
+        put_matrix(st + plan.wout, dtype, t->data.data(), D, F * C, nullptr, &colmap);
+        GET("encoder.conv_subsample.out.0.bias", D); put_f32(st + plan.bout, t->data.data(), D);
+    }
+    std::vector<const HostTensor *> wpos;
+    for (int l = 0; l < m->L; ++l) {
+        const LayerW &w = plan.layers[l];
+        auto key = [&](const char *suffix) { snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.%s", l, suffix); return std::string(buf); };
+        for (int i = 0; i < 2; ++i) {
+            const std::string pre = std::string(i == 0 ? "0" : "3") + ".module.sequential.";
+            GET(key((pre + "0.weight").c_str()), D); put_f32(st + w.ffn[i].ln_g, t->data.data(), D);
+            GET(key((pre + "0.bias").c_str()), D); put_f32(st + w.ffn[i].ln_b, t->data.data(), D);
+            GET(key((pre + "1.linear.weight").c_str()), ff, D); put_matrix(st + w.ffn[i].w1, dtype, t->data.data(), ff, D);
+            GET(key((pre + "1.linear.bias").c_str()), ff); put_f32(st + w.ffn[i].b1, t->data.data(), ff);
+            GET(key((pre + "4.linear.weight").c_str()), D, ff); put_matrix(st + w.ffn[i].w2, dtype, t->data.data(), D, ff);
+            GET(key((pre + "4.linear.bias").c_str()), D); put_f32(st + w.ffn[i].b2, t->data.data(), D);
+        }
+        GET(key("1.module.layer_norm.weight"), D); put_f32(st + w.a_ln_g, t->data.data(), D);
+        GET(key("1.module.layer_norm.bias"), D); put_f32(st + w.a_ln_b, t->data.data(), D);
+        const char *proj[3] = {"query", "key", "value"};
+        for (int j = 0; j < 3; ++j) {
+            snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.1.module.attention.%s_proj.linear.weight", l, proj[j]);
+            GET(std::string(buf), D, D); put_matrix(st + w.wqkv + (size_t)j * D * D * esize(dtype), dtype, t->data.data(), D, D);
+            snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.1.module.attention.%s_proj.linear.bias", l, proj[j]);
+            GET(std::string(buf), D); put_f32(st + w.bqkv + (size_t)j * D * 4, t->data.data(), D);
+        }
+        GET(key("1.module.attention.u_bias"), h, dh); put_f32(st + w.ub, t->data.data(), D);
+        GET(key("1.module.attention.v_bias"), h, dh); put_f32(st + w.vb, t->data.data(), D);
+        GET(key("1.module.attention.pos_proj.linear.weight"), D, D); wpos.push_back(t);
+        GET(key("1.module.attention.out_proj.linear.weight"), D, D); put_matrix(st + w.wo, dtype, t->data.data(), D, D);
+        GET(key("1.module.attention.out_proj.linear.bias"), D); put_f32(st + w.bo, t->data.data(), D);
+        GET(key("2.module.sequential.0.weight"), D); put_f32(st + w.c_ln_g, t->data.data(), D);
+        GET(key("2.module.sequential.0.bias"), D); put_f32(st + w.c_ln_b, t->data.data(), D);
+        {   // GLU interleave: packed row 32j + c <- value row 16j + c ; packed row 32j + 16 + c <- gate row D + 16j + c
+            std::vector<int> rowmap((size_t)2 * D);
+            for (int n = 0; n < 2 * D; ++n) {
+                const int tn = n >> 4, c = n & 15, j = tn >> 1;
+                rowmap[n] = (tn & 1) ? D + 16 * j + c : 16 * j + c;
+            }
+            GET(key("2.module.sequential.2.conv.weight"), 2 * D, D, 1); put_matrix(st + w.wpw1, dtype, t->data.data(), 2 * D, D, &rowmap);
+            GET(key("2.module.sequential.2.conv.bias"), 2 * D);
+            for (int n = 0; n < 2 * D; ++n) ((float *)(st + w.bpw1))[n] = t->data[rowmap[n]];
+        }
+        {   // BatchNorm (eval) folded into the depthwise taps: s = gamma / sqrt(var + eps)
+            const HostTensor *wd, *g, *b, *mu, *var;
+            if ((rc = expect_shape(m, key("2.module.sequential.4.conv.weight"), {D, 1, k}, &wd))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.weight"), {D}, &g))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.bias"), {D}, &b))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.running_mean"), {D}, &mu))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.running_var"), {D}, &var))) return rc;
+            float *tw = (float *)(st + w.dww), *tb = (float *)(st + w.dwb);
+            for (int c = 0; c < D; ++c) {
+                const float s = g->data[c] / sqrtf(var->data[c] + 1e-5f);
+                for (int tau = 0; tau < k; ++tau) tw[(size_t)tau * D + c] = wd->data[(size_t)c * k + tau] * s;
+                tb[c] = b->data[c] - mu->data[c] * s;
+            }
+        }
+        GET(key("2.module.sequential.7.conv.weight"), D, D, 1); put_matrix(st + w.wpw2, dtype, t->data.data(), D, D);
+        GET(key("2.module.sequential.7.conv.bias"), D); put_f32(st + w.bpw2, t->data.data(), D);
+        GET(key("4.weight"), D); put_f32(st + w.f_ln_g, t->data.data(), D);
+        GET(key("4.bias"), D); put_f32(st + w.f_ln_b, t->data.data(), D);
+    }
+    GET("decoder.weight", m->ncls, D); put_matrix(st + plan.wdec, dtype, t->data.data(), m->ncls, D);
+    GET("decoder.bias", m->ncls); put_f32(st + plan.bdec, t->data.data(), m->ncls);
+#undef GET
+    if ((rc = alloc_blob(m, dtype))) return rc;
+    HIP_TRY(hipMemcpy(m->blob, st, plan.total, hipMemcpyHostToDevice));
+    rc = dtype == COCR_BF16 ? compute_pos_tables<bf16_t>(m, wpos) : compute_pos_tables<float>(m, wpos);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return COCR_OK;
+}
+
+// P_l = PE Wpos_l^T for all 9999 relative positions (embedding.py:35-56 table, attention.py:62,85
+// projection), computed once on the device in fp32 and stored head-padded in the compute dtype.
+template <typename T> static int compute_pos_tables(cocr_model *m, const std::vector<const HostTensor *> &wpos) {
+    const int D = m->D, R = COCR_POS_ROWS, maxlen = (R + 1) / 2;
+    std::vector<float> pe((size_t)R * D);
+    for (int r = 0; r < R; ++r) {
+        const float pos = (float)(maxlen - 1 - r);           // +4999 ... -4999
+        for (int i = 0; i < D; i += 2) {
+            const float div = expf((float)i * (float)(-(log(10000.0) / D)));
+            const float ang = pos * div;
+            pe[(size_t)r * D + i] = sinf(ang);
+            if (i + 1 < D) pe[(size_t)r * D + i + 1] = cosf(ang);
+        }
+    }
+    float *d_pe = nullptr, *d_w = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_pe, pe.size() * 4));
+    HIP_TRY(hipMalloc((void **)&d_w, (size_t)D * D * 4));
+    HIP_TRY(hipMemcpy(d_pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < m->L; ++l) {
+        HIP_TRY(hipMemcpy(d_w, wpos[l]->data.data(), (size_t)D * D * 4, hipMemcpyHostToDevice));
+        EpiPosTable<T> epi{(T *)(m->blob + m->plan.layers[l].ptab), m->dh, m->dhp, m->heads};
+        launch_gemm<float>(0, d_pe, D, d_w, D, R, D, D, epi);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    HIP_TRY(hipFree(d_pe));
+    HIP_TRY(hipFree(d_w));
+    return COCR_OK;
+}
+
+// ------------------------------------------------------------------------------------ workspace
+static int ws_alloc(cocr_model *m, void **p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 256));
+    m->ws_allocs.push_back(*p);
+    return COCR_OK;
+}
+
+extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    if (m->dtype < 0) return fail(COCR_ESTATE, "model not finalized");
+    if (N < 1 || W < 1) return fail(COCR_EINVAL, "empty batch");
+    if (N <= m->capN && W <= m->capW) return COCR_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    N = std::max(N, m->capN); W = std::max(W, m->capW);
+    free_workspace(m);
+    const size_t es = esize(m->dtype);
+    int T = W;
+    for (int i = 0; i < m->snum; ++i) T = out_len1(T);
+    int T2 = out_len1(out_len1(W));                 // frames after the fused first two stages
+    const size_t M = (size_t)N * T, Tp = round_up(T, 32);
+    int rc;
+    const size_t zbytes = (size_t)N * T2 * m->feats[1] * m->C * es;
+    if ((rc = ws_alloc(m, &m->z_a, zbytes))) return rc;
+    if ((rc = ws_alloc(m, &m->z_b, zbytes))) return rc;
+    if ((rc = ws_alloc(m, (void **)&m->x, M * m->D * 4))) return rc;
+    if ((rc = ws_alloc(m, &m->xn, M * m->D * es))) return rc;
+    if ((rc = ws_alloc(m, &m->hid, M * m->ff * es))) return rc;
+    m->qkv_bytes = (size_t)N * m->heads * Tp * m->dhp * es;
+    if ((rc = ws_alloc(m, &m->q, m->qkv_bytes))) return rc;
+    if ((rc = ws_alloc(m, &m->k, m->qkv_bytes))) return rc;
+    if ((rc = ws_alloc(m, &m->vt, m->qkv_bytes))) return rc;
+    if ((rc = ws_alloc(m, &m->ctx, M * m->D * es))) return rc;
+    if ((rc = ws_alloc(m, &m->glu, M * m->D * es))) return rc;
+    if ((rc = ws_alloc(m, &m->dwo, M * m->D * es))) return rc;
+    m->capN = N; m->capW = W;
+    return COCR_OK;
+}
+
+// ------------------------------------------------------------------------------------ debug / profile
+template <typename T> __global__ void to_f32_kernel(const T *in, float *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = to_f32(in[i]);
+}
+template <typename T> static int tap(cocr_model *m, hipStream_t s, const std::string &name, const T *src, size_t n) {
+    if (!m->debug) return COCR_OK;
+    float *dst = nullptr;
+    HIP_TRY(hipMalloc((void **)&dst, n * 4));
+    hipLaunchKernelGGL((to_f32_kernel<T>), dim3(256), dim3(256), 0, s, src, dst, n);
+    HIP_TRY(hipStreamSynchronize(s));
+    auto it = m->taps.find(name);
+    if (it != m->taps.end()) (void)hipFree(it->second.first);
+    m->taps[name] = {dst, (int64_t)n};
+    return COCR_OK;
+}
+
+extern "C" int cocr_set_debug(cocr_model *m, int on) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    m->debug = on != 0;
+    if (!on) clear_taps(m);
+    return COCR_OK;
+}
+extern "C" int cocr_debug_tap(cocr_model *m, const char *name, float *host_out, int64_t max_elems, int64_t *n_elems) {
+    if (!m || !name) return fail(COCR_EINVAL, "null argument");
+    auto it = m->taps.find(name);
+    if (it == m->taps.end()) return fail(COCR_EINVAL, "no tap '%s' (debug off, or stage not run)", name);
+    if (n_elems) *n_elems = it->second.second;
+    if (host_out) {
+        if (max_elems < it->second.second) return fail(COCR_EINVAL, "tap '%s' has %lld elements", name, (long long)it->second.second);
+        HIP_TRY(hipMemcpy(host_out, it->second.first, it->second.second * 4, hipMemcpyDeviceToHost));
+    }
+    return COCR_OK;
+}
+
+struct ProfScope {
+    cocr_model *m; hipStream_t s; ProfRec r; bool on;
+    ProfScope(cocr_model *m_, hipStream_t s_, int fam) : m(m_), s(s_), on(m_->profile) {
+        if (!on) return;
+        r.fam = fam;
+        auto get = [&]() { hipEvent_t e; if (m->ev_pool.empty()) { (void)hipEventCreate(&e); } else { e = m->ev_pool.back(); m->ev_pool.pop_back(); } return e; };
+        r.a = get(); r.b = get();
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); m->prof.push_back(r); } }
+};
+
+extern "C" int cocr_profile(cocr_model *m, int on) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    m->profile = on != 0;
+    for (auto &r : m->prof) { m->ev_pool.push_back(r.a); m->ev_pool.push_back(r.b); }
+    m->prof.clear();
+    return COCR_OK;
+}
+extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, double *ms, int64_t *launches, int max_entries) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double sum[FAM_COUNT] = {0};
+    int64_t cnt[FAM_COUNT] = {0};
+    for (auto &r : m->prof) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        sum[r.fam] += t; cnt[r.fam]++;
+    }
+    std::string s;
+    int n = 0;
+    for (int f = 0; f < FAM_COUNT && n < max_entries; ++f) {
+        if (!cnt[f]) continue;
+        s += FAMILIES[f]; s += '\n';
+        ms[n] = sum[f] / (double)cnt[f]; launches[n] = cnt[f];
+        ++n;
+    }
+    if (names && names_len) { strncpy(names, s.c_str(), names_len - 1); names[names_len - 1] = 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------ forward
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+template <typename T, typename TIn>
+static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, float *logits, hipStream_t s) {
+    const BlobPlan &P = m->plan;
+    const unsigned char *B = m->blob;
+    auto F32 = [&](size_t off) { return (const float *)(B + off); };
+    auto WT = [&](size_t off) { return (const T *)(B + off); };
+    const int D = m->D, C = m->C, ff = m->ff, heads = m->heads, dh = m->dh, dhp = m->dhp;
+    const int T1 = out_len1(W), T2 = out_len1(T1), F1 = m->feats[0], F2 = m->feats[1];
+    int rc;
+
+    // ---- frontend: conv.0 + ReLU + depthwise conv.2 fused, then pointwise conv.3 + ReLU as a GEMM over channels
+    T *za = (T *)m->z_a, *zb = (T *)m->z_b;
+    {
+        ProfScope ps(m, s, FAM_CONV12);
+        const int TB = std::max(1, 256 / C);
+        const size_t lds = (size_t)(4 * TB + 3) * (H + 8) * 4;
+        hipLaunchKernelGGL((frontend_conv12_kernel<T, TIn>), dim3(ceil_div(T2, TB), N), dim3(256), lds, s, lines, H, W, T1, F1, T2, F2, C,
+                           F32(P.w0), F32(P.b0), F32(P.stages[0].dw_w), F32(P.stages[0].dw_b), za, TB);
+        LAUNCH_CHECK();
+    }
+    if ((rc = tap<T>(m, s, "front.z2", za, (size_t)N * T2 * F2 * C))) return rc;
+    {
+        ProfScope ps(m, s, FAM_FPW);
+        EpiBiasAct<T, ACT_RELU> epi{zb, C, F32(P.stages[0].pw_b)};
+        launch_gemm<T>(s, za, C, WT(P.stages[0].pw_w), C, N * T2 * F2, C, C, epi);
+        LAUNCH_CHECK();
+    }
+    if ((rc = tap<T>(m, s, "front.z3", zb, (size_t)N * T2 * F2 * C))) return rc;
+    int Tc = T2, Fc = F2;
+    T *zcur = zb, *zoth = za;
+    for (int st = 1; st < m->snum - 1; ++st) {           // further (depthwise s2, pointwise, ReLU) stages
+        const int To = out_len1(Tc), Fo = m->feats[st + 1];
+        {
+            ProfScope ps(m, s, FAM_FDW);
+            hipLaunchKernelGGL((dw3x3s2_kernel<T>), dim3(1024), dim3(256), 0, s, zcur, N, Tc, Fc, To, Fo, C, F32(P.stages[st].dw_w),
+                               F32(P.stages[st].dw_b), zoth);
+            LAUNCH_CHECK();
+        }
+        {
+            ProfScope ps(m, s, FAM_FPW);
+            EpiBiasAct<T, ACT_RELU> epi{zcur, C, F32(P.stages[st].pw_b)};
+            launch_gemm<T>(s, zoth, C, WT(P.stages[st].pw_w), C, N * To * Fo, C, C, epi);
+            LAUNCH_CHECK();
+        }
+        Tc = To; Fc = Fo;
+    }
+    const int Tn = Tc, F = Fc, M = N * Tn, Tp = round_up(Tn, 32);
+    {   // flatten (b,t,(f,c)) is a view of the channel-last tensor; output linear writes the fp32 residual stream
+        ProfScope ps(m, s, FAM_FOUT);
+        EpiStoreF32 epi{m->x, D, F32(P.bout)};
+        launch_gemm<T>(s, zcur, F * C, WT(P.wout), F * C, M, D, F * C, epi);
+        LAUNCH_CHECK();
+    }
+    if ((rc = tap<float>(m, s, "front.y", m->x, (size_t)M * D))) return rc;
+
+    T *xn = (T *)m->xn, *hid = (T *)m->hid, *q = (T *)m->q, *k = (T *)m->k, *vt = (T *)m->vt, *ctx = (T *)m->ctx, *glu = (T *)m->glu,
+      *dwo = (T *)m->dwo;
+    if (m->vtN != N || m->vtT != Tn) {   // pad rows / pad dims of q, k, vt must read as zero for this shape
+        HIP_TRY(hipMemsetAsync(q, 0, m->qkv_bytes, s));
+        HIP_TRY(hipMemsetAsync(k, 0, m->qkv_bytes, s));
+        HIP_TRY(hipMemsetAsync(vt, 0, m->qkv_bytes, s));
+        m->vtN = N; m->vtT = Tn;
+    }
+    const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
+    const float scale = 1.0f / sqrtf((float)dh);
+    char nm[64];
+    auto ffn = [&](const FfnW &w) -> int {
+        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.b1)}; launch_gemm<T>(s, xn, D, WT(w.w1), D, M, ff, D, e); LAUNCH_CHECK(); }
+        { ProfScope ps(m, s, FAM_FFN_DOWN); EpiResidual e{m->x, D, F32(w.b2), ffr}; launch_gemm<T>(s, hid, ff, WT(w.w2), ff, M, D, ff, e); LAUNCH_CHECK(); }
+        return COCR_OK;
+    };
+    auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
+        ProfScope ps(m, s, FAM_LN);
+        launch_layernorm<T>(s, m->x, M, D, F32(g1), F32(b1), write_f32 ? m->x : nullptr, g2 >= 0 ? F32((size_t)g2) : nullptr,
+                            b2 >= 0 ? F32((size_t)b2) : nullptr, xn);
+        LAUNCH_CHECK();
+        return COCR_OK;
+    };
+    for (int l = 0; l < m->L; ++l) {
+        const LayerW &w = P.layers[l];
+        if (l == 0 && (rc = ln(w.ffn[0].ln_g, w.ffn[0].ln_b, false, -1, -1))) return rc;
+        // FFN, half-step residual (feed_forward.py:45-52, encoder.py:68-75)
+        if ((rc = ffn(w.ffn[0]))) return rc;
+        snprintf(nm, sizeof nm, "l%d.ffn1", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        // MHSA (attention.py:143-151)
+        if ((rc = ln(w.a_ln_g, w.a_ln_b, false, -1, -1))) return rc;
+        { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, vt, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp}; launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e); LAUNCH_CHECK(); }
+        {
+            ProfScope ps(m, s, FAM_ATTN);
+            dim3 grid(ceil_div(Tn, 64), N * heads);
+#define ATTN(DHP) hipLaunchKernelGGL((relpos_attention_kernel<T, DHP>), grid, dim3(256), 0, s, q, k, vt, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)
+            if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
+#undef ATTN
+            LAUNCH_CHECK();
+        }
+        if (m->debug) {
+            snprintf(nm, sizeof nm, "l%d.q", l); if ((rc = tap<T>(m, s, nm, q, m->qkv_bytes / sizeof(T)))) return rc;
+            snprintf(nm, sizeof nm, "l%d.k", l); if ((rc = tap<T>(m, s, nm, k, m->qkv_bytes / sizeof(T)))) return rc;
+            snprintf(nm, sizeof nm, "l%d.vt", l); if ((rc = tap<T>(m, s, nm, vt, m->qkv_bytes / sizeof(T)))) return rc;
+            snprintf(nm, sizeof nm, "l%d.ctx", l); if ((rc = tap<T>(m, s, nm, ctx, (size_t)M * D))) return rc;
+        }
+        { ProfScope ps(m, s, FAM_AOUT); EpiResidual e{m->x, D, F32(w.bo), 1.0f}; launch_gemm<T>(s, ctx, D, WT(w.wo), D, M, D, D, e); LAUNCH_CHECK(); }
+        snprintf(nm, sizeof nm, "l%d.mhsa", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        // conv module (convolution.py:135-148)
+        if ((rc = ln(w.c_ln_g, w.c_ln_b, false, -1, -1))) return rc;
+        { ProfScope ps(m, s, FAM_GLU); EpiGLU<T> e{glu, D, F32(w.bpw1)}; launch_gemm<T>(s, xn, D, WT(w.wpw1), D, M, 2 * D, D, e); LAUNCH_CHECK(); }
+        {
+            ProfScope ps(m, s, FAM_DW);
+            constexpr int TT = 16;
+            const size_t lds = (size_t)(TT + m->ksz - 1) * 128 * 2 * sizeof(T);
+            hipLaunchKernelGGL((dwconv_bn_silu_kernel<T, TT>), dim3(ceil_div(Tn, TT), N, ceil_div(D, 256)), dim3(128), lds, s, glu, Tn, D, m->ksz,
+                               F32(w.dww), F32(w.dwb), dwo);
+            LAUNCH_CHECK();
+        }
+        if (m->debug) {
+            snprintf(nm, sizeof nm, "l%d.glu", l); if ((rc = tap<T>(m, s, nm, glu, (size_t)M * D))) return rc;
+            snprintf(nm, sizeof nm, "l%d.dw", l); if ((rc = tap<T>(m, s, nm, dwo, (size_t)M * D))) return rc;
+        }
+        { ProfScope ps(m, s, FAM_PW2); EpiResidual e{m->x, D, F32(w.bpw2), 1.0f}; launch_gemm<T>(s, dwo, D, WT(w.wpw2), D, M, D, D, e); LAUNCH_CHECK(); }
+        snprintf(nm, sizeof nm, "l%d.conv", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        // second FFN
+        if ((rc = ln(w.ffn[1].ln_g, w.ffn[1].ln_b, false, -1, -1))) return rc;
+        if ((rc = ffn(w.ffn[1]))) return rc;
+        snprintf(nm, sizeof nm, "l%d.ffn2", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        // block-final LayerNorm (encoder.py:99), chained with the next block's first LayerNorm
+        if (l + 1 < m->L) {
+            const LayerW &nx = P.layers[l + 1];
+            if ((rc = ln(w.f_ln_g, w.f_ln_b, true, (long)nx.ffn[0].ln_g, (long)nx.ffn[0].ln_b))) return rc;
+        } else {
+            if ((rc = ln(w.f_ln_g, w.f_ln_b, m->debug, -1, -1))) return rc;
+        }
+        snprintf(nm, sizeof nm, "l%d.out", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+    }
+    {   // decoder nn.Linear (pred.py:90,121): logits fp32
+        ProfScope ps(m, s, FAM_DEC);
+        EpiStoreF32 e{logits, m->ncls, F32(P.bdec)};
+        launch_gemm<T>(s, xn, D, WT(P.wdec), D, M, m->ncls, D, e);
+        LAUNCH_CHECK();
+    }
+    return COCR_OK;
+}
+
+extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W, const int32_t *in_lens,
+                            float *logits, int32_t *out_lens, void *stream) {
+    if (!m || !lines || !logits) return fail(COCR_EINVAL, "null argument");
+    if (m->dtype < 0 || !m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (H != m->H) return fail(COCR_EINVAL, "line height %d does not match the model's height %d", H, m->H);
+    if (N < 1 || W < 1) return fail(COCR_EINVAL, "empty batch");
+    if (cocr_out_len(W, m->hp.subsampling_factor) > 4900) return fail(COCR_EUNSUPPORTED, "more than 4900 output frames");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = cocr_reserve(m, N, W);
+    if (rc) return rc;
+    if (in_lens && out_lens)
+        for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
+    hipStream_t s = (hipStream_t)stream;
+    if (m->dtype == COCR_BF16) {
+        if (line_dtype == COCR_F32) return forward_impl<bf16_t, float>(m, (const float *)lines, N, H, W, logits, s);
+        if (line_dtype == COCR_U8) return forward_impl<bf16_t, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
+    } else {
+        if (line_dtype == COCR_F32) return forward_impl<float, float>(m, (const float *)lines, N, H, W, logits, s);
+        if (line_dtype == COCR_U8) return forward_impl<float, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
+    }
+    return fail(COCR_EINVAL, "line dtype must be COCR_F32 or COCR_U8");
+}
+
+// ------------------------------------------------------------------------------------ CTC
+static int upload_lens(cocr_model *m, const int32_t *lens, int N, hipStream_t s) {
+    if (N > m->lens_cap) {
+        if (m->d_lens) (void)hipFree(m->d_lens);
+        HIP_TRY(hipMalloc((void **)&m->d_lens, (size_t)N * 4));
+        m->lens_cap = N;
+    }
+    HIP_TRY(hipMemcpyAsync(m->d_lens, lens, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    return COCR_OK;
+}
+
+extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T, int ncls, const int32_t *out_lens, int32_t *labels,
+                               int32_t *starts, int32_t *ends, float *conf, int32_t *counts, int max_per_line, void *stream) {
+    if (!m || !logits || !out_lens || !labels || !starts || !ends || !conf || !counts) return fail(COCR_EINVAL, "null argument");
+    if (N < 1 || T < 1 || ncls < 1 || max_per_line < 1) return fail(COCR_EINVAL, "empty problem");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = upload_lens(m, out_lens, N, s);
+    if (rc) return rc;
+    if ((size_t)N * T > m->ctc_cap) {
+        if (m->ctc_lab) (void)hipFree(m->ctc_lab);
+        if (m->ctc_val) (void)hipFree(m->ctc_val);
+        HIP_TRY(hipMalloc((void **)&m->ctc_lab, (size_t)N * T * 4));
+        HIP_TRY(hipMalloc((void **)&m->ctc_val, (size_t)N * T * 4));
+        m->ctc_cap = (size_t)N * T;
+    }
+    ProfScope ps(m, s, FAM_GREEDY);
+    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(N), dim3(256), 0, s, logits, T, ncls, m->d_lens, labels, starts, ends, conf, counts,
+                       max_per_line, m->ctc_lab, m->ctc_val);
+    LAUNCH_CHECK();
+    return COCR_OK;
+}
+
+extern "C" int cocr_ctc_beam(cocr_model *, const float *, int, int, int, const int32_t *, int32_t *, int32_t *, int32_t *, float *, int32_t *,
+                             int, int, void *) {
+    return fail(COCR_EUNSUPPORTED, "cocr_ctc_beam: not built yet");
+}

@@ -1,0 +1,151 @@
+// Convolution kernels of the path (all VALU, fp32 arithmetic):
+//   * frontend_conv12_kernel: Conv2d(1,C,3,s2,p1)+ReLU fused with the depthwise Conv2d(C,C,3,s2,p1)
+//     (reference conformer/convolution.py:192-205); the (B,C,W/2,H/2) intermediate is never written.
+//   * dw3x3s2_kernel: the depthwise stage of further subsampling steps (subsampling_factor > 4).
+//   * dwconv_bn_silu_kernel: the conv module's DepthwiseConv1d(k) + BatchNorm1d(eval) + SiLU
+//     (convolution.py:140-142) with the BatchNorm folded into taps and bias at load time.
+#pragma once
+#include "common.hip.h"
+
+// ---- frontend F1+F2 ---------------------------------------------------------------------------
+// Geometry: X[b][r][w] image row r (height H), column w (width W).  The reference
+// transposes the line to (W,H) before the 2-D convs, so kernel dim 0 runs along image width (time).
+//   Z1[c][t1][f1] = relu(b0[c] + sum_{dt,df} w0[c][dt][df] X[2 f1 + df - 1][2 t1 + dt - 1])   t1 < T1, f1 < F1
+//   Z2[c][t][f]   = b2[c] + sum_{dt,df} w2[c][dt][df] Z1[c][2t + dt - 1][2f + df - 1]          (zero outside)
+// Output layout (B, T, F, C): channel fastest, so the pointwise conv that follows is a plain
+// row-major GEMM over (B*T*F) rows and the flatten (b,t,(f,c)) feeding the output linear is a view.
+//
+// Work split: a workgroup takes TB consecutive t of one line; its 256 threads are (t_local, channel)
+// pairs.  The 4*TB+3 image columns the group needs are staged once in LDS as fp32 (transposed,
+// [column][row+4], zero borders), every thread walks f = 0..F-1 keeping the previous Z1 column.
+template <typename TIn> __device__ __forceinline__ float pixel_to_f32(TIn v);
+template <> __device__ __forceinline__ float pixel_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float pixel_to_f32<uint8_t>(uint8_t v) { return (float)v / 255.0f; }
+
+template <typename T, typename TIn>
+__global__ __launch_bounds__(256) void frontend_conv12_kernel(const TIn *__restrict__ X, int H, int W, int T1, int F1, int Tn, int F, int C,
+                                                              const float *__restrict__ w0, const float *__restrict__ b0,
+                                                              const float *__restrict__ w2, const float *__restrict__ b2,
+                                                              T *__restrict__ Z2, int TB) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [ncols][H + 8]
+    const int b = blockIdx.y, t0 = blockIdx.x * TB;
+    const int ncols = 4 * TB + 3, HS = H + 8;
+    const int col0 = 4 * t0 - 3;
+    const TIn *Xb = X + (size_t)b * H * W;
+    for (int i = threadIdx.x; i < ncols * HS; i += blockDim.x) {
+        const int ci = i / HS, rr = i - ci * HS;     // LDS row rr <-> image row rr - 4
+        const int w = col0 + ci, r = rr - 4;
+        xs[i] = (w >= 0 && w < W && r >= 0 && r < H) ? pixel_to_f32<TIn>(Xb[(size_t)r * W + w]) : 0.0f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TB * C; idx += blockDim.x) {
+        const int tl = idx / C, c = idx - tl * C;
+        const int t = t0 + tl;
+        if (t >= Tn) continue;
+        float k0[9], k2[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { k0[i] = w0[c * 9 + i]; k2[i] = w2[c * 9 + i]; }
+        const float bias0 = b0[c], bias2 = b2[c];
+        // Z1 column at (t1 = 2t-1+a, f1): image columns 2 t1 + dt - 1 = col0 + 4 tl + 2a + dt
+        const float *xc = xs + (4 * tl) * HS + 4;     // xc[(2a+dt)*HS + r] = X[r][4t-3+2a+dt]
+        auto z1 = [&](int a, int f1) -> float {
+            const int t1 = 2 * t - 1 + a;
+            if (t1 < 0 || t1 >= T1 || f1 < 0 || f1 >= F1) return 0.0f;   // zero padding of the second conv
+            float s = bias0;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) s += k0[dt * 3 + df] * xc[(2 * a + dt) * HS + 2 * f1 + df - 1];
+            return fmaxf(s, 0.0f);
+        };
+        float prev[3] = {0.f, 0.f, 0.f};              // Z1[.][f1 = 2f - 1], f = 0: outside
+        T *out = Z2 + (((size_t)b * Tn + t) * F) * C + c;
+        for (int f = 0; f < F; ++f) {
+            float s = bias2;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float m = z1(a, 2 * f), n = z1(a, 2 * f + 1);
+                s += k2[a * 3 + 0] * prev[a] + k2[a * 3 + 1] * m + k2[a * 3 + 2] * n;
+                prev[a] = n;
+            }
+            out[(size_t)f * C] = from_f32<T>(s);
+        }
+    }
+}
+
+// ---- extra depthwise 3x3 stride-2 stage on channel-last (B,T,F,C) -> (B,T2,F2,C), bias, no activation
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3s2_kernel(const T *__restrict__ in, int B, int Ti, int Fi, int To, int Fo, int C,
+                                                      const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out) {
+    const size_t total = (size_t)B * To * Fo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int f = (int)(r % Fo); r /= Fo;
+        const int t = (int)(r % To);
+        const int b = (int)(r / To);
+        float s = bias[c];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int ti = 2 * t + dt - 1, fi = 2 * f + df - 1;
+                if (ti >= 0 && ti < Ti && fi >= 0 && fi < Fi)
+                    s += w[c * 9 + dt * 3 + df] * to_f32(in[(((size_t)b * Ti + ti) * Fi + fi) * C + c]);
+            }
+        out[i] = from_f32<T>(s);
+    }
+}
+
+// ---- conv module: depthwise k-tap FIR along time + folded BatchNorm + SiLU ----------------------
+//   u[b][t][c] = silu(bias'[c] + sum_tau w'[tau][c] g[b][t + tau - (k-1)/2][c]),  zero outside [0,T) of the
+//   PADDED batch (the reference pads the batch tensor, not the individual line: SURVEY A.1b).
+// Workgroup = TT output frames x 256 channels of one line; the TT+k-1 input frames are staged in LDS
+// (coalesced over channels); each of 128 threads owns two adjacent channels.  HBM-bound: algorithmic
+// bytes = one read + one write of the (B,T,D) operand.
+template <typename T> struct Pair;
+template <> struct Pair<bf16_t> { typedef bf16x2 type; };
+template <> struct Pair<float> { typedef f32x2 type; };
+
+template <typename T, int TT>
+__global__ __launch_bounds__(128) void dwconv_bn_silu_kernel(const T *__restrict__ g, int Tn, int D, int k,
+                                                             const float *__restrict__ w, const float *__restrict__ bias,
+                                                             T *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    typedef typename Pair<T>::type P2;
+    P2 *win = reinterpret_cast<P2 *>(dw_smem);                 // [TT + k - 1][128] channel pairs
+    const int b = blockIdx.y, t0 = blockIdx.x * TT, c0 = blockIdx.z * 256;
+    const int pad = (k - 1) / 2, rows = TT + k - 1;
+    const int c = c0 + 2 * threadIdx.x;
+    const bool live = c < D;                                   // D is even
+    const T *gb = g + (size_t)b * Tn * D;
+    for (int r = 0; r < rows; ++r) {
+        const int t = t0 + r - pad;
+        P2 v; v[0] = (T)0.0f; v[1] = (T)0.0f;
+        if (live && t >= 0 && t < Tn) v = *reinterpret_cast<const P2 *>(gb + (size_t)t * D + c);
+        win[r * 128 + threadIdx.x] = v;
+    }
+    // each thread reads back only what it wrote itself: no barrier needed
+    if (!live) return;
+    float a0[TT], a1[TT];
+    const float bb0 = bias[c], bb1 = bias[c + 1];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) { a0[i] = bb0; a1[i] = bb1; }
+    for (int tau = 0; tau < k; ++tau) {
+        const float w0 = w[(size_t)tau * D + c], w1 = w[(size_t)tau * D + c + 1];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const P2 v = win[(i + tau) * 128 + threadIdx.x];
+            a0[i] += w0 * to_f32(v[0]);
+            a1[i] += w1 * to_f32(v[1]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const int t = t0 + i;
+        if (t < Tn) {
+            P2 o; o[0] = from_f32<T>(silu_f(a0[i])); o[1] = from_f32<T>(silu_f(a1[i]));
+            *reinterpret_cast<P2 *>(out + ((size_t)b * Tn + t) * D + c) = o;
+        }
+    }
+}

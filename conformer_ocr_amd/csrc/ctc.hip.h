@@ -1,0 +1,67 @@
+// CTC decoding on the device -- replaces the per-line host loop of the reference
+// (pred.py:137-145,157-164,172-178; model.py:163-168: D2H of all logits, then
+// kraken.lib.ctc_decoder.greedy_decoder per line in Python).  Only the compact label records
+// leave the GPU.  Integer outputs (labels, starts, ends, counts) are exact; conf is the max over a
+// run of the winning logit (greedy) / softmax probability (beam).
+#pragma once
+#include "common.hip.h"
+
+// ---- greedy: argmax per frame (first index on ties, like numpy), merge runs, drop blank ---------
+// One workgroup per line.  Phase 1: each wave takes frames t = wave, wave+4, ...: lanes stride the
+// classes (coalesced), keep (value, index) with strict > so the lowest index wins inside a lane, then a
+// butterfly that prefers the larger value and, on equality, the lower index.  Phase 2: one wave
+// scans the frame labels in chunks of 64: a frame opens a run if its label differs from its
+// predecessor's; ballot + popcount give each non-blank run its output slot; the run's end and
+// confidence are found by walking forward.  HBM-bound: algorithmic bytes = N*T*ncls*4 read.
+#define COCR_CTC_MAX_T 8192
+
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float *__restrict__ logits, int T, int ncls,
+                                                         const int32_t *__restrict__ lens,
+                                                         int32_t *__restrict__ labels, int32_t *__restrict__ starts,
+                                                         int32_t *__restrict__ ends, float *__restrict__ conf,
+                                                         int32_t *__restrict__ counts, int max_per_line,
+                                                         int32_t *__restrict__ scratch_lab, float *__restrict__ scratch_val) {
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int len = min(max(lens[n], 0), T);
+    const float *lg = logits + (size_t)n * T * ncls;
+    int32_t *flab = scratch_lab + (size_t)n * T;      // per-frame argmax label
+    float *fval = scratch_val + (size_t)n * T;        // per-frame max logit
+    for (int t = wave; t < len; t += 4) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < ncls; c += 64) {
+            const float v = lg[(size_t)t * ncls + c];
+            if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { flab[t] = bi; fval[t] = best; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wave != 0) return;
+    int emitted = 0;
+    for (int base = 0; base < len; base += 64) {
+        const int t = base + lane;
+        const bool in = t < len;
+        const int lab = in ? flab[t] : 0;
+        const int prev = (in && t > 0) ? flab[t - 1] : -1;
+        const bool open = in && lab != 0 && lab != prev;
+        const unsigned long long mask = __ballot(open);
+        const int slot = emitted + __popcll(mask & ((1ull << lane) - 1ull));
+        if (open && slot < max_per_line) {
+            int e = t;
+            float mx = fval[t];
+            while (e + 1 < len && flab[e + 1] == lab) { ++e; mx = fmaxf(mx, fval[e]); }
+            const size_t o = (size_t)n * max_per_line + slot;
+            labels[o] = lab; starts[o] = t; ends[o] = e; conf[o] = mx;
+        }
+        emitted += __popcll(mask);
+    }
+    if (lane == 0) counts[n] = emitted;
+}

@@ -1,0 +1,172 @@
+"""Thin Python handle over a `cocr_model` (include/cocr.h).  torch is used only to own device
+memory and streams; every computation is a call through the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spec import HParams
+
+DTYPES = {'bf16': _lib.BF16, 'bfloat16': _lib.BF16, 'fp32': _lib.F32, 'f32': _lib.F32, 'float32': _lib.F32}
+
+
+def _stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class HipRecognizer:
+    """One packed model on one GPU."""
+
+    def __init__(self, hp: HParams, device: torch.device, compute_dtype: str = 'bf16'):
+        if compute_dtype not in DTYPES:
+            raise ValueError(f'compute_dtype must be one of {sorted(DTYPES)}')
+        self.lib = _lib.load()
+        self.hp = hp
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('the HIP recognizer runs on a GPU device only (no CPU fallback)')
+        self.dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device('cuda', self.dev_index)
+        self.compute_dtype = compute_dtype
+        chp = _lib.HParamsC(num_classes=hp.num_classes, height=hp.height, encoder_dim=hp.encoder_dim,
+                            num_encoder_layers=hp.num_encoder_layers, num_attention_heads=hp.num_attention_heads,
+                            feed_forward_expansion_factor=hp.feed_forward_expansion_factor,
+                            conv_expansion_factor=hp.conv_expansion_factor, conv_kernel_size=hp.conv_kernel_size,
+                            half_step_residual=int(bool(hp.half_step_residual)),
+                            subsampling_conv_channels=hp.subsampling_conv_channels,
+                            subsampling_factor=hp.subsampling_factor)
+        h = C.c_void_p()
+        _lib.check(self.lib.cocr_create(C.byref(chp), self.dev_index, C.byref(h)))
+        self._h = h
+        self.ready = False
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                self.lib.cocr_destroy(h)
+            except Exception:
+                pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state(self, state: Mapping[str, 'np.ndarray | torch.Tensor'], strict: bool = True) -> None:
+        """`state`: keys of `nn.state_dict()` (`encoder.*`, `decoder.*`)."""
+        for name, val in state.items():
+            if name.endswith('num_batches_tracked'):
+                continue
+            arr = val.detach().cpu().float().numpy() if isinstance(val, torch.Tensor) else np.asarray(val, dtype=np.float32)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _lib.check(self.lib.cocr_set_tensor(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), _lib.F32, arr.ndim, shape))
+        if strict:
+            buf = C.create_string_buffer(1 << 16)
+            n = self.lib.cocr_missing_tensors(self._h, buf, len(buf))
+            if n:
+                raise RuntimeError('Missing key(s) in state_dict: ' + ', '.join(buf.value.decode().split()))
+
+    def finalize(self) -> None:
+        _lib.check(self.lib.cocr_finalize(self._h, DTYPES[self.compute_dtype]))
+        self.ready = True
+
+    def finalize_empty(self) -> None:
+        _lib.check(self.lib.cocr_finalize_empty(self._h, DTYPES[self.compute_dtype]))
+        self.ready = True
+
+    def weight_blob(self) -> torch.Tensor:
+        """The packed device blob as a uint8 torch view (for an RCCL broadcast through torch.distributed)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self.lib.cocr_weight_blob(self._h, C.byref(p), C.byref(n)))
+
+        class _Mem:   # __cuda_array_interface__ view of library-owned memory; `owner` keeps the model alive
+            def __init__(s, owner):
+                s.owner = owner
+                s.__cuda_array_interface__ = {'shape': (n.value,), 'typestr': '|u1', 'data': (p.value, False), 'version': 2}
+        return torch.as_tensor(_Mem(self), device=self.device)
+
+    # ---- compute -------------------------------------------------------------------------------
+    def out_len(self, w: int) -> int:
+        return int(self.lib.cocr_out_len(int(w), self.hp.subsampling_factor))
+
+    def reserve(self, n: int, w: int) -> None:
+        _lib.check(self.lib.cocr_reserve(self._h, int(n), int(w)))
+
+    def forward(self, lines: torch.Tensor, lens: Sequence[int]) -> Tuple[torch.Tensor, np.ndarray]:
+        """lines: (N,H,W) float32 or uint8 on this device, contiguous.  Returns (logits (N,T,ncls) f32 device, out_lens int32 host)."""
+        if not self.ready:
+            raise RuntimeError('model not finalized')
+        if lines.device != self.device:
+            raise RuntimeError(f'line batch lives on {lines.device}, the model on {self.device}')
+        if lines.dim() != 3:
+            raise ValueError('expected a (N,H,W) batch')
+        if lines.dtype == torch.uint8:
+            ldt = _lib.U8
+        else:
+            lines = lines.float()
+            ldt = _lib.F32
+        lines = lines.contiguous()
+        N, H, W = lines.shape
+        in_lens = np.ascontiguousarray(np.asarray(lens, dtype=np.int32).reshape(-1))
+        if in_lens.shape[0] != N:
+            raise ValueError('lens must have one entry per line')
+        out_lens = np.zeros(N, dtype=np.int32)
+        T = self.out_len(W)
+        logits = torch.empty((N, T, self.hp.num_classes), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_forward(self._h, C.c_void_p(lines.data_ptr()), ldt, N, H, W,
+                                             in_lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(logits.data_ptr()),
+                                             out_lens.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(self.device)))
+        return logits, out_lens
+
+    def _decode(self, fn, logits: torch.Tensor, out_lens, extra=()) -> List[List[Tuple[int, int, int, float]]]:
+        if logits.device != self.device or logits.dtype != torch.float32:
+            raise RuntimeError('logits must be float32 on the model device')
+        logits = logits.contiguous()
+        N, T, ncls = logits.shape
+        lens = np.ascontiguousarray(np.asarray(out_lens, dtype=np.int32).reshape(-1))
+        ints = torch.empty((3, N, T), dtype=torch.int32, device=self.device)
+        conf = torch.empty((N, T), dtype=torch.float32, device=self.device)
+        counts = torch.empty((N,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(fn(self._h, C.c_void_p(logits.data_ptr()), N, T, ncls, lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                          C.c_void_p(ints[0].data_ptr()), C.c_void_p(ints[1].data_ptr()), C.c_void_p(ints[2].data_ptr()),
+                          C.c_void_p(conf.data_ptr()), C.c_void_p(counts.data_ptr()), T, *extra, _stream_ptr(self.device)))
+        ints_h = ints.cpu().numpy()
+        conf_h = conf.cpu().numpy()
+        cnt = counts.cpu().numpy()
+        out = []
+        for n in range(N):
+            c = int(cnt[n])
+            out.append([(int(ints_h[0, n, i]), int(ints_h[1, n, i]), int(ints_h[2, n, i]), float(conf_h[n, i])) for i in range(c)])
+        return out
+
+    def ctc_greedy(self, logits: torch.Tensor, out_lens) -> List[List[Tuple[int, int, int, float]]]:
+        return self._decode(self.lib.cocr_ctc_greedy, logits, out_lens)
+
+    def ctc_beam(self, logits: torch.Tensor, out_lens, beam: int = 16) -> List[List[Tuple[int, int, int, float]]]:
+        return self._decode(self.lib.cocr_ctc_beam, logits, out_lens, extra=(int(beam),))
+
+    # ---- test / measurement hooks ---------------------------------------------------------------
+    def set_debug(self, on: bool) -> None:
+        _lib.check(self.lib.cocr_set_debug(self._h, int(on)))
+
+    def tap(self, name: str) -> np.ndarray:
+        n = C.c_int64()
+        _lib.check(self.lib.cocr_debug_tap(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        _lib.check(self.lib.cocr_debug_tap(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
+
+    def profile(self, on: bool) -> None:
+        _lib.check(self.lib.cocr_profile(self._h, int(on)))
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * 64)()
+        cnt = (C.c_int64 * 64)()
+        n = _lib.check(self.lib.cocr_profile_read(self._h, names, len(names), ms, cnt, 64))
+        keys = names.value.decode().split('\n')[:n]
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(keys)}

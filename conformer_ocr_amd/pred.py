@@ -1,0 +1,236 @@
+"""
+conformer_ocr_amd.pred
+~~~~~~~~~~~~~~~~~~~~~~
+
+Recognition inference: `PytorchRecognitionModel` with the surface of the reference class
+(reference conformer_ocr/pred.py:50-210 -- constructor arguments, attributes `nn`, `codec`,
+`ctc_decoder`, `height`, `channels`, `width`; methods `forward`, `predict`, `predict_string`,
+`predict_labels`, `load_safetensors`, `load_checkpoint`), backed by the gfx950 kernels behind the C
+ABI of include/cocr.h.  torch holds the parameters (state-dict compatible with reference
+checkpoints) and owns device memory; no layer of the network is evaluated by torch.
+"""
+from __future__ import annotations
+
+import io
+import json
+import logging
+import tarfile
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .codec import PytorchCodec
+from .ctc_decoder import BeamDecoder, GreedyDecoder, greedy_decoder
+from .engine import HipRecognizer
+from .spec import HParams, encoder_state_spec
+
+logger = logging.getLogger(__name__)
+
+
+class _Holder(nn.Module):
+    """Parameter container: no forward, only the reference's module tree for its state-dict keys."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError('parameters only: the network runs in libcocr_hip.so')
+
+
+def _build_param_tree(spec) -> nn.Module:
+    root = _Holder()
+    for name, (shape, kind) in spec.items():
+        parts = name.split('.')
+        mod = root
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, _Holder())
+            mod = getattr(mod, p)
+        leaf = parts[-1]
+        if kind == 'param':
+            if len(shape) >= 2:
+                t = torch.empty(shape).uniform_(-0.05, 0.05)
+            else:
+                t = torch.ones(shape) if leaf == 'weight' else torch.zeros(shape)
+            mod.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
+        elif kind == 'buffer':
+            mod.register_buffer(leaf, torch.ones(shape) if leaf == 'running_var' else torch.zeros(shape))
+        else:
+            mod.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
+    return root
+
+
+class PytorchRecognitionModel(nn.Module):
+    def __init__(self,
+                 num_classes: int,
+                 height: int,
+                 encoder_dim: int,
+                 num_encoder_layers: int,
+                 num_attention_heads: int,
+                 feed_forward_expansion_factor: int,
+                 conv_expansion_factor: int,
+                 input_dropout_p: float,
+                 feed_forward_dropout_p: float,
+                 attention_dropout_p: float,
+                 conv_dropout_p: float,
+                 conv_kernel_size: int,
+                 half_step_residual: bool,
+                 subsampling_conv_channels: int,
+                 subsampling_factor: int,
+                 codec: PytorchCodec,
+                 ctc_decoder=greedy_decoder,
+                 **kwargs):
+        """
+        Inference version of a conformer_ocr RecognitionModel (pred.py:51-98).  Dropout
+        probabilities are accepted and ignored (inference); unknown keyword arguments are ignored
+        like in the reference, except `compute_dtype` ('bf16' default, or 'fp32').
+        """
+        super().__init__()
+        self.hparams_record = HParams(num_classes=num_classes, height=height, encoder_dim=encoder_dim,
+                                      num_encoder_layers=num_encoder_layers, num_attention_heads=num_attention_heads,
+                                      feed_forward_expansion_factor=feed_forward_expansion_factor,
+                                      conv_expansion_factor=conv_expansion_factor, conv_kernel_size=conv_kernel_size,
+                                      half_step_residual=bool(half_step_residual),
+                                      subsampling_conv_channels=subsampling_conv_channels,
+                                      subsampling_factor=subsampling_factor)
+        encoder = _build_param_tree(encoder_state_spec(self.hparams_record))
+        decoder = nn.Linear(encoder_dim, num_classes, bias=True)
+        for p in decoder.parameters():
+            p.requires_grad_(False)
+        self.nn = nn.ModuleDict({'encoder': encoder,
+                                 'decoder': decoder})
+
+        self.codec = codec
+        self.ctc_decoder = ctc_decoder
+        self.height = height
+        self.channels = 1
+        self.width = 0
+        self.compute_dtype = kwargs.get('compute_dtype', 'bf16')
+        self._engine: Optional[HipRecognizer] = None
+        self._engine_sig = None
+
+    # ------------------------------------------------------------------ device model
+    def _signature(self, device: torch.device):
+        return (str(device), self.compute_dtype, tuple((t.data_ptr(), t._version) for t in self.nn.state_dict().values()))
+
+    def engine(self, device: Optional[torch.device] = None) -> HipRecognizer:
+        """The packed device model, (re)built when the parameters or the device changed."""
+        if device is None:
+            device = next(self.nn.parameters()).device
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('PytorchRecognitionModel (HIP) needs a GPU: move the model / line batch to a cuda device; '
+                               'there is no CPU fallback')
+        sig = self._signature(device)
+        if self._engine is None or sig != self._engine_sig:
+            eng = HipRecognizer(self.hparams_record, device, self.compute_dtype)
+            eng.load_state({k: v for k, v in self.nn.state_dict().items()}, strict=True)
+            eng.finalize()
+            self._engine, self._engine_sig = eng, sig
+        return self._engine
+
+    def adopt_engine(self, eng: HipRecognizer) -> None:
+        """Use an already packed device model (e.g. one whose weights arrived by RCCL broadcast)."""
+        self._engine = eng
+        self._engine_sig = self._signature(eng.device)
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, line: torch.Tensor, lens: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """
+        Performs a forward pass on a torch tensor of one or more lines with
+        shape (N, C, H, W) and returns the logits (N, W', num_classes) [a torch tensor on the
+        line's device, as the reference returns despite its docstring] and the int32 output
+        sequence lengths (pred.py:101-122).  `lens` is required, as in the reference
+        (calc_length(None) raises there).
+        """
+        if lens is None:
+            raise TypeError('lens is required (the reference raises in calc_length for lens=None)')
+        if line.dim() != 4 or line.shape[1] != 1:
+            raise ValueError(f'expected a (N,1,H,W) line batch, got {tuple(line.shape)}')
+        eng = self.engine(line.device if line.is_cuda else None)
+        with torch.no_grad():
+            probits, out_lens = eng.forward(line.squeeze(1), torch.as_tensor(lens).cpu().numpy())
+        return probits, torch.from_numpy(out_lens)
+
+    def _label_records(self, line: torch.Tensor, lens: torch.Tensor) -> List[List[Tuple[int, int, int, float]]]:
+        o, olens = self.forward(line, lens)
+        if isinstance(self.ctc_decoder, GreedyDecoder):
+            return self._engine.ctc_greedy(o, olens.numpy())
+        if isinstance(self.ctc_decoder, BeamDecoder):
+            return self._engine.ctc_beam(o, olens.numpy(), self.ctc_decoder.beam_size)
+        # a user-supplied decoder: the reference's own host loop (pred.py:158-162)
+        o = o.transpose(1, 2).cpu().float().numpy()
+        return [self.ctc_decoder(seq[:, :int(seq_len)]) for seq, seq_len in zip(o, olens)]
+
+    def predict(self, line: torch.Tensor, lens: Optional[torch.Tensor] = None) -> List[List[Tuple[str, int, int, float]]]:
+        """
+        Forward pass + decoding as lists of (string, start, end, confidence) tuples, one list per
+        line -- what the reference's docstring promises (pred.py:124-136; its body calls the codec
+        object itself, which kraken's codec does not support).
+        """
+        return [self.codec.decode(locs) for locs in self._label_records(line, lens)]
+
+    def predict_string(self, line: torch.Tensor, lens: Optional[torch.Tensor] = None) -> List[str]:
+        """
+        Forward pass on a (N, C, H, W) batch; returns one string per line, batch order
+        preserved (pred.py:148-164).
+        """
+        return [''.join(x[0] for x in self.codec.decode(locs)) for locs in self._label_records(line, lens)]
+
+    def predict_labels(self, line: torch.tensor, lens: torch.Tensor = None) -> List[List[Tuple[int, int, int, float]]]:
+        """
+        Forward pass on a (N, C, H, W) batch; returns per line a list of tuples
+        (class, start, end, max) (pred.py:166-178).
+        """
+        return self._label_records(line, lens)
+
+    @classmethod
+    def load_safetensors(cls, path, **kwargs):
+        """
+        Loads a safetensors archive: tar with `metadata.json` {codec, hyper_params} and
+        `model.safetensors` = `nn.state_dict()` (pred.py:180-195).
+        """
+        import safetensors.torch
+        with tarfile.open(path, 'r') as tf:
+            metadata = json.load(tf.extractfile('metadata.json'))
+            if 'codec' not in metadata:
+                raise ValueError('No codec in metadata record')
+            codec = PytorchCodec(metadata['codec'])
+            if 'hyper_params' not in metadata:
+                raise ValueError('No hyperparameters in metadata record')
+            net = cls(**{**metadata['hyper_params'], **kwargs}, codec=codec)
+            weights = safetensors.torch.load(tf.extractfile('model.safetensors').read())
+        net.nn.load_state_dict(weights)
+        return net.eval()
+
+    @classmethod
+    def load_checkpoint(cls, path, **kwargs):
+        """
+        Loads a lightning checkpoint (pred.py:197-210): `state_dict` (keys `nn.encoder.*`,
+        `nn.decoder.*`), `hyper_parameters`, `TextLineDataModule.codec`.
+        """
+        state_dict = torch.load(path, map_location='cpu', weights_only=True)
+        if 'TextLineDataModule' not in state_dict:
+            raise ValueError('Checkpoint does not contain data module state.')
+        codec = PytorchCodec(state_dict['TextLineDataModule']['codec'])
+        if 'hyper_parameters' not in state_dict:
+            raise ValueError('No hyperparameters in state_dict')
+        net = cls(**{**state_dict['hyper_parameters'], **kwargs}, codec=codec)
+        net.load_state_dict(state_dict['state_dict'], strict=False)
+        return net.eval()
+
+
+def save_safetensors(net: PytorchRecognitionModel, path, extra_metadata: Optional[Dict] = None) -> None:
+    """Writes the archive format `load_safetensors` reads (the reference's converter, pred.py:213-254,
+    does not run: SURVEY A.4)."""
+    import safetensors.torch
+    hp = net.hparams_record.as_dict()
+    hp.update(input_dropout_p=0.1, feed_forward_dropout_p=0.1, attention_dropout_p=0.1, conv_dropout_p=0.1)
+    meta = {'codec': net.codec.c2l, 'hyper_params': hp}
+    meta.update(extra_metadata or {})
+    blob = safetensors.torch.save({k: v.detach().cpu().contiguous() for k, v in net.nn.state_dict().items()})
+    mj = json.dumps(meta).encode()
+    with tarfile.open(path, 'w') as tf:
+        for name, data in (('model.safetensors', blob), ('metadata.json', mj)):
+            ti = tarfile.TarInfo(name)
+            ti.size = len(data)
+            tf.addfile(ti, io.BytesIO(data))

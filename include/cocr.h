@@ -1,0 +1,137 @@
+/*
+ * cocr.h -- C ABI of libcocr_hip.so: the MI355X (gfx950) implementation of the
+ * recognition hot path of mittagessen/conformer_ocr:
+ *
+ *     line batch (N,1,H,W) -> conformer encoder -> linear decoder -> CTC decode
+ *
+ * The reference has no FFI for this path: it is the Python class
+ * `PytorchRecognitionModel` (reference conformer_ocr/pred.py:50-210).  The host
+ * class `conformer_ocr_amd.pred.PytorchRecognitionModel` keeps that class's
+ * surface and binds these entry points through ctypes; each entry point cites
+ * the reference lines whose work it takes over.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every function
+ * returns 0 on success or a negative COCR_E* code, with a thread-local message
+ * behind cocr_last_error(); the caller owns every buffer it passes in; the
+ * library owns weights and workspace; a cocr_model is bound to one device and
+ * must not be used from two host threads at once.  `stream` is a hipStream_t
+ * (NULL = the default stream); all device work of a call is enqueued on it and
+ * the call returns without synchronising unless stated.
+ */
+#ifndef COCR_H
+#define COCR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cocr_model cocr_model;
+
+/* element types of buffers crossing the boundary */
+enum { COCR_F32 = 0, COCR_BF16 = 1, COCR_U8 = 2, COCR_I64 = 3 };
+
+enum {
+    COCR_OK = 0,
+    COCR_EINVAL = -1,      /* bad argument / shape / name   -> ValueError   */
+    COCR_ESTATE = -2,      /* call out of order             -> RuntimeError */
+    COCR_EHIP = -3,        /* HIP runtime error             -> RuntimeError */
+    COCR_EUNSUPPORTED = -4 /* hyper-parameters outside what the kernels cover */
+};
+
+/* The shape-determining constructor arguments of PytorchRecognitionModel
+ * (pred.py:51-66); dropout probabilities are inference no-ops and not passed. */
+typedef struct {
+    int32_t num_classes;
+    int32_t height;
+    int32_t encoder_dim;
+    int32_t num_encoder_layers;
+    int32_t num_attention_heads;
+    int32_t feed_forward_expansion_factor;
+    int32_t conv_expansion_factor;
+    int32_t conv_kernel_size;
+    int32_t half_step_residual;
+    int32_t subsampling_conv_channels;
+    int32_t subsampling_factor;
+} cocr_hparams;
+
+const char *cocr_last_error(void);
+const char *cocr_version(void);
+
+/* Replaces the module construction of pred.py:70-91 (ConformerEncoder + nn.Linear decoder).
+ * Validates like the reference constructors do (attention.py:53, convolution.py:132-133,177-178). */
+int cocr_create(const cocr_hparams *hp, int device, cocr_model **out);
+void cocr_destroy(cocr_model *m);
+
+/* Replaces nn.Module.load_state_dict (pred.py:194,209): hands one state-dict entry to the model.
+ * `name` is the reference key below `nn.` ("encoder.layers.0...", "decoder.weight"); `host` is
+ * read during the call (copied).  dtype COCR_F32, or COCR_I64 for num_batches_tracked (ignored). */
+int cocr_set_tensor(cocr_model *m, const char *name, const void *host, int dtype, int ndim, const int64_t *shape);
+
+/* Names of tensors still missing, '\n'-separated, into buf (for strict loading); returns the count. */
+int cocr_missing_tensors(cocr_model *m, char *buf, size_t buflen);
+
+/* Packs the weights for the kernels and uploads them: BatchNorm folded into the depthwise taps
+ * (convolution.py:140-141, eval mode), positional projection P = PE Wpos^T precomputed for the full
+ * 9999-row table (embedding.py:35-66, attention.py:62,85,146), GLU / flatten permutations.
+ * compute_dtype: COCR_BF16 (bf16 operands, fp32 accumulate, fp32 residual stream) or COCR_F32.
+ * Synchronises the device. */
+int cocr_finalize(cocr_model *m, int compute_dtype);
+
+/* Multi-GPU start-up: a rank that receives its weights by broadcast allocates the packed blob
+ * without filling it, hands (ptr, bytes) to its collective library (RCCL broadcast from the rank
+ * that ran cocr_finalize), and is then ready.  The blob layout depends only on (hparams, dtype). */
+int cocr_finalize_empty(cocr_model *m, int compute_dtype);
+int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes);
+
+/* calc_length (convolution.py:240-247) with k=3, s=2, p=1 repeated log2(subsampling_factor) times. */
+int32_t cocr_out_len(int32_t in_len, int32_t subsampling_factor);
+
+/* Pre-allocates workspace for batches up to N lines of width W (otherwise cocr_forward grows it on
+ * demand, which synchronises and must not happen inside a stream capture). */
+int cocr_reserve(cocr_model *m, int N, int W);
+
+/* PytorchRecognitionModel.forward (pred.py:101-122): lines (N,H,W) [the (N,1,H,W) batch with the
+ * singleton channel dropped; W fastest], DEVICE memory of type line_dtype (COCR_F32 in [0,1] or
+ * COCR_U8, read as u8/255).  in_lens (N) HOST int32 pixel widths.  logits: DEVICE float32
+ * (N,T,num_classes) with T = cocr_out_len(W).  out_lens: HOST int32 (N), written before return.
+ * The padded region is processed like the reference does: no masking. */
+int cocr_forward(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W,
+                 const int32_t *in_lens, float *logits, int32_t *out_lens, void *stream);
+
+/* Replaces the per-line host loop `self.ctc_decoder(seq[:, :seq_len])` with
+ * kraken.lib.ctc_decoder.greedy_decoder (pred.py:138-145,158-164,173-178; model.py:163-168):
+ * per line argmax over classes (first index on ties), merge runs, drop blank (0).
+ * logits DEVICE float32 (N,T,ncls); out_lens HOST int32 (N).  Outputs DEVICE, caller-owned:
+ * labels/starts/ends int32 (N,max_per_line), conf float32 (N,max_per_line) = max over the run of the
+ * label's logit, counts int32 (N).  A line emits at most ceil(len/1) runs; max_per_line >= T is safe;
+ * excess runs are counted but not stored. */
+int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T, int ncls, const int32_t *out_lens,
+                    int32_t *labels, int32_t *starts, int32_t *ends, float *conf, int32_t *counts,
+                    int max_per_line, void *stream);
+
+/* CTC prefix beam search (kraken.lib.ctc_decoder.beam_decoder's algorithm on log-softmax(logits);
+ * semantics fixed in oracle/ctc_ref.py::beam_decoder).  Same buffers as cocr_ctc_greedy; conf is a
+ * softmax probability.  beam <= 32. */
+int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, int ncls, const int32_t *out_lens,
+                  int32_t *labels, int32_t *starts, int32_t *ends, float *conf, int32_t *counts,
+                  int max_per_line, int beam, void *stream);
+
+/* Test taps: with debug on, cocr_forward keeps a float32 copy of every stage output
+ * ("front.z2", "front.z3", "front.y", "l<i>.ffn1|mhsa|conv|ffn2|out", "l<i>.q|k|vt|ctx|glu|dw").
+ * cocr_debug_tap copies one to HOST memory; *n_elems receives its element count. */
+int cocr_set_debug(cocr_model *m, int on);
+int cocr_debug_tap(cocr_model *m, const char *name, float *host_out, int64_t max_elems, int64_t *n_elems);
+
+/* Kernel timing hook for bench.py's roofline leg: average device time (ms) per launch of each
+ * kernel family over the forwards run since cocr_profile(m,1), measured with HIP events on the
+ * forward's own stream.  Names are '\n'-separated in `names`; ms[i], launches[i] per family. */
+int cocr_profile(cocr_model *m, int on);
+int cocr_profile_read(cocr_model *m, char *names, size_t names_len, double *ms, int64_t *launches, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COCR_H */
