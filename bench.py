@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--streams', type=int, default=1, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -117,23 +118,46 @@ def main():
     torch.cuda.set_device(dev)
 
     hp = synth.hparams(args.config)
-    eng = HipRecognizer(hp, dev, args.dtype)
+    S = max(1, args.streams)
+    engines = [HipRecognizer(hp, dev, args.dtype) for _ in range(S)]
+    eng = engines[0]
     state = None
     if rank == 0:
         state = synth.make_state_dict(hp, seed=1236, decoder_gain=8.0)
-        eng.load_state(state)
-        eng.finalize()
+        for e in engines:
+            e.load_state(state)
+            e.finalize()
     else:
-        eng.finalize_empty()
+        for e in engines:
+            e.finalize_empty()
     if world > 1:
         from conformer_ocr_amd.dist import broadcast_weights
-        broadcast_weights(eng, src=0)
+        for e in engines:
+            broadcast_weights(e, src=0)
 
     # per-rank independent synthetic batches, resident in HBM (float32 (N,H,W), what the reference's loader hands over)
     img, lens = synth.make_lines(args.batch, hp.height, args.width, seed=1000 + rank)
     x = torch.from_numpy(img[:, 0]).to(dev)
     lens32 = lens.astype(np.int32)
-    eng.reserve(args.batch, args.width)
+    for e in engines:
+        e.reserve(args.batch, args.width)
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+
+    def run_steps(n):
+        """n steps; step i is enqueued on stream i % S (forward + greedy decode + D2H of the label records) and its
+        records are collected S steps later, so S independent batches overlap on the GPU."""
+        pending, recs = [], None
+        for i in range(n):
+            e = engines[i % S]
+            with torch.cuda.stream(streams[i % S]):
+                logits, out_lens = e.forward(x, lens32)
+                pending.append((e, e.ctc_greedy_async(logits, out_lens)))
+            if len(pending) >= S:
+                pe, h = pending.pop(0)
+                recs = pe.collect(h)
+        for pe, h in pending:
+            recs = pe.collect(h)
+        return recs
 
     def step():
         logits, out_lens = eng.forward(x, lens32)
@@ -144,12 +168,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        recs = step()
+    recs = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -197,7 +219,7 @@ def main():
             'config': {'workload': f'{args.config}: conformer D={hp.encoder_dim} L={hp.num_encoder_layers} heads={hp.num_attention_heads} '
                                    f'sub_ch={hp.subsampling_conv_channels}, batch {args.batch} x 96x{args.width} per GPU, '
                                    f'forward + CTC greedy', 'lines_per_step_per_gpu': args.batch, 'gflop_per_line': round(gflop, 3),
-                       'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast'},
+                       'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast', 'streams_per_gpu': S},
             'achieved_tflops_whole_path': round(value * gflop / 1e3, 2),
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
             'labels_emitted_last_step': int(sum(len(r) for r in recs)),

@@ -7,58 +7,119 @@
 // P is the per-layer table PE Wpos^T precomputed for all 9999 relative positions (row CEN = 4999 is
 // relative position 0), so the reference's pad/view "relative shift" is just the index CEN - (i - j).
 //
-// Decomposition: workgroup = one (line, head, 64-query tile); each of its 4 waves owns 16 queries and
-// walks the keys in tiles of 32 with an online softmax.  All products are computed TRANSPOSED (keys /
-// positions / head-dim on the MFMA row side, the wave's 16 queries on the column side), so that a
-// query's scores live in one lane column: the softmax statistics are per-lane scalars (plus two
-// cross-quad shuffles) and the exponentiated scores are already the B operand of the P.V product.
-//   S^T  (32 keys x 16 q)   = K_tile      . (Q+u)^T     2 row tiles x dhp/32 k-chunks
-//   R^T  (48 rows x 16 q)   = P_band      . (Q+v)^T     band rows rbase .. rbase+46, rbase = CEN-(i0+15)+j0
+// Decomposition: workgroup = one (line, head, 64-query tile); each of its 4 waves owns 16 queries.  The
+// keys are walked in tiles of 64: K tile, V tile and the 128-row band of P that the (64 queries x 64 keys)
+// pair touches are staged in LDS once per tile (global -> registers while the previous tile is being
+// computed -> LDS), and every wave reads its fragments from there.  All products are computed TRANSPOSED
+// (keys / positions / head-dim on the MFMA row side, the wave's 16 queries on the column side): a query's
+// scores live in one lane column, so the online-softmax statistics are per-lane scalars (plus two
+// cross-quad shuffles) and the exponentiated scores are directly the B operand of the P.V product:
+//   S^T  (32 keys x 16 q)   = K_sub       . (Q+u)^T     2 row tiles x dhp/32 k-chunks
+//   R^T  (48 rows x 16 q)   = P_band      . (Q+v)^T     band rows of this (wave, 32-key sub-tile)
 //   pos^T[jl][il]           = R^T[15 - il + jl][il]      the "shift": through a per-wave LDS tile
-//   O^T  (dhp x 16 q)      += V^T_tile    . P^T          k-chunk = the 32 keys of the tile
-// Operands come straight from global memory (K, V^T and the band of P are L2 resident: one (b,h) is
-// 2 x 38 KB at T=300); layouts q,k [B][h][Tp][dhp], vt [B][h][dhp][Tp], P [9999][h][dhp].
+//   O^T  (dhp x 16 q)      += V^T_sub     . P^T          V^T fragments by ds_read_b64_tr_b16 (bf16) from the
+//                                                        row-major V tile: no transposed copy of V anywhere
+// Layouts: q, k, v [B][h][Tp][dhp] (head dim zero-padded to a multiple of 32), P [9999][h][dhp].
 #pragma once
 #include "common.hip.h"
 
 #define COCR_POS_CENTER 4999
 #define COCR_POS_ROWS 9999
 
+// V^T fragment of one k-chunk (32 keys) for head-dim row tile d: element e of quad g <-> key 16 (e>>2) + 4g + (e&3)
+// (the same permutation the exponentiated scores have in their accumulator registers).
+__device__ __forceinline__ bf16x8 load_vt_frag(const unsigned char *vtile, int stride, int key0, int d, int il, int g, bf16_t) {
+    // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a 4x16 block and
+    // receives column (lane & 15) of the 4 rows.  Block rows = keys key0 + 4g + q, block columns = dims 16 d ..+15.
+    const unsigned char *p0 = vtile + (key0 + 4 * g + (il >> 2)) * stride + (16 * d + 4 * (il & 3)) * 2;
+    typedef __attribute__((address_space(3))) bf16x4 *lp;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0 + 16 * stride));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ f32x8 load_vt_frag(const unsigned char *vtile, int stride, int key0, int d, int il, int g, float) {
+    f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        r[e] = *reinterpret_cast<const float *>(vtile + (key0 + 16 * (e >> 2) + 4 * g + (e & 3)) * stride + (16 * d + il) * 4);
+    return r;
+}
+
 template <typename T, int DHP>   // DHP = padded head dim, multiple of 32
-__global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ vt,
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
                                                                const T *__restrict__ ptab, const float *__restrict__ ub,
                                                                const float *__restrict__ vb, T *__restrict__ ctx,
                                                                int Tn, int Tp, int heads, int dh, float scale) {
-    constexpr int KC = DHP / 32;     // k-chunks over the head dim
-    constexpr int DT = DHP / 16;     // 16-row tiles of O^T
-    constexpr int SK = 20;           // LDS row stride (floats) of the shift tile: conflict-free write and skewed read
-    __shared__ float skew[4][48 * SK];
+    constexpr int KC = DHP / 32;                      // k-chunks over the head dim
+    constexpr int DT = DHP / 16;                      // 16-row tiles of O^T
+    constexpr int SK = 20;                            // row stride (floats) of the shift tile: conflict-free write and skewed read
+    constexpr int RB = DHP * (int)sizeof(T);          // bytes per operand row
+    constexpr int RS = RB + 16;                       // padded LDS row
+    constexpr int CPR = RB / 16;                      // 16-byte chunks per row
+    constexpr int KV_IT = 64 * CPR / 256, P_IT = 128 * CPR / 256;
     typedef typename FragOf<T>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+    unsigned char *ks = att_smem, *vs = ks + 64 * RS, *ps = vs + 64 * RS;
+    float *skew = reinterpret_cast<float *>(ps + 128 * RS);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int il = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / heads, hh = bh - b * heads;
-    const int i0 = blockIdx.x * 64 + wave * 16;
-    // queries beyond T only exist to keep the wave uniform: they read row T-1 and store nothing
-    const int iq = min(i0 + il, Tn - 1);
+    const int i0b = blockIdx.x * 64, i0 = i0b + wave * 16;
+    const int iq = min(i0 + il, Tn - 1);              // queries beyond T read row T-1 and store nothing
 
-    const T *qrow = q + ((size_t)bh * Tp + iq) * DHP;
     const T *kbase = k + (size_t)bh * Tp * DHP;
-    const T *vbase = vt + (size_t)bh * DHP * Tp;
-    const int prow = heads * DHP;                      // elements per table row
+    const T *vbase = v + (size_t)bh * Tp * DHP;
+    const int prow = heads * DHP;
     const T *pbase = ptab + hh * DHP;
+
+    // tile loads: K/V rows j0 .. j0+63 (clamped), band rows B0 .. B0+127 (clamped), B0 = CEN - (i0b + 63) + j0
+    uint4 rk[KV_IT], rv[KV_IT], rp[P_IT];
+    auto load_tile = [&](int j0) {
+        const int B0 = COCR_POS_CENTER - (i0b + 63) + j0;
+#pragma unroll
+        for (int it = 0; it < KV_IT; ++it) {
+            const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
+            const size_t off = (size_t)min(j0 + row, Tn - 1) * DHP + ch * (16 / (int)sizeof(T));
+            rk[it] = *reinterpret_cast<const uint4 *>(kbase + off);
+            rv[it] = *reinterpret_cast<const uint4 *>(vbase + off);
+        }
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
+            const int pr = min(max(B0 + row, 0), COCR_POS_ROWS - 1);
+            rp[it] = *reinterpret_cast<const uint4 *>(pbase + (size_t)pr * prow + ch * (16 / (int)sizeof(T)));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < KV_IT; ++it) {
+            const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
+            *reinterpret_cast<uint4 *>(ks + row * RS + ch * 16) = rk[it];
+            *reinterpret_cast<uint4 *>(vs + row * RS + ch * 16) = rv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
+            *reinterpret_cast<uint4 *>(ps + row * RS + ch * 16) = rp[it];
+        }
+    };
+    load_tile(0);
 
     // B operands: (q + u) and (q + v) of this lane's query, per k-chunk; padded dims stay zero
     frag_t qu[KC], qv[KC];
+    {
+        const T *qrow = q + ((size_t)bh * Tp + iq) * DHP;
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const frag_t qq = load_frag(qrow + c * 32 + 8 * g);
+        for (int c = 0; c < KC; ++c) {
+            const frag_t qq = load_frag(qrow + c * 32 + 8 * g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = c * 32 + 8 * g + j;
-            const float x = to_f32(qq[j]);
-            qu[c][j] = d < dh ? from_f32<T>(x + ub[hh * dh + d]) : (T)0.0f;
-            qv[c][j] = d < dh ? from_f32<T>(x + vb[hh * dh + d]) : (T)0.0f;
+            for (int j = 0; j < 8; ++j) {
+                const int d = c * 32 + 8 * g + j;
+                const float x = to_f32(qq[j]);
+                qu[c][j] = d < dh ? from_f32<T>(x + ub[hh * dh + d]) : (T)0.0f;
+                qv[c][j] = d < dh ? from_f32<T>(x + vb[hh * dh + d]) : (T)0.0f;
+            }
         }
     }
 
@@ -66,76 +127,74 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
     for (int d = 0; d < DT; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    float *sk = skew[wave];
+    float *sk = skew + wave * 48 * SK;
 
-    for (int j0 = 0; j0 < Tn; j0 += 32) {
-        // ---- content scores, transposed: rows = keys j0 + 16 tt + (4g + reg), column = query il
-        f32x4 sc[2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int jr = min(j0 + 16 * tt + il, Tn - 1);        // A-operand row of this lane (clamped; masked below)
-#pragma unroll
-            for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(kbase + (size_t)jr * DHP + c * 32 + 8 * g), qu[c], sc[tt]);
-        }
-        // ---- positional scores on the band of P this (query tile, key tile) pair touches
-        const int rbase = COCR_POS_CENTER - (i0 + 15) + j0;
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) {
-            f32x4 rp = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int pr = min(max(rbase + 16 * mt + il, 0), COCR_POS_ROWS - 1);
-#pragma unroll
-            for (int c = 0; c < KC; ++c) rp = mma16(load_frag(pbase + (size_t)pr * prow + c * 32 + 8 * g), qv[c], rp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sk[(16 * mt + 4 * g + r) * SK + il] = rp[r];
-        }
+    for (int j0 = 0; j0 < Tn; j0 += 64) {
+        __syncthreads();                       // every wave is done with the previous tile
+        store_tile();
         __syncthreads();
-        // ---- shift, scale, mask padded keys of the last tile
-        float tmax = -INFINITY;
+        if (j0 + 64 < Tn) load_tile(j0 + 64);  // in flight during the compute below
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int js = j0 + 32 * s2;       // first key of this 32-key sub-tile
+            if (js >= Tn) break;               // uniform over the workgroup
+            // ---- content scores, transposed: rows = keys js + 16 tt + (4g + reg), column = query il
+            f32x4 sc[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jl = 16 * tt + 4 * g + r;
-                float s = (sc[tt][r] + sk[(15 - il + jl) * SK + il]) * scale;
-                s = (j0 + jl < Tn) ? s : -INFINITY;
-                sc[tt][r] = s;
-                tmax = fmaxf(tmax, s);
+            for (int tt = 0; tt < 2; ++tt) {
+                sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const unsigned char *kr = ks + (32 * s2 + 16 * tt + il) * RS;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr) + c * 32 + 8 * g), qu[c], sc[tt]);
             }
-        __syncthreads();
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);                    // finite: key j0 is always valid
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        frag_t pb;
+            // ---- positional scores: band rows lb + 16 mt + il of the staged band, lb = (48 - 16 wave) + 32 s2
+            const int lb = 48 - 16 * wave + 32 * s2;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+            for (int mt = 0; mt < 3; ++mt) {
+                f32x4 rr = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const unsigned char *pr = ps + (lb + 16 * mt + il) * RS;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[tt][r] - m_new);
-                psum += p;
-                pb[4 * tt + r] = from_f32<T>(p);
+                for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr) + c * 32 + 8 * g), qv[c], rr);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sk[(16 * mt + 4 * g + r) * SK + il] = rr[r];
             }
-        l_run = l_run * alpha + psum;
-        // ---- O^T = alpha O^T + V^T_tile . P^T ; k order inside the chunk: element 4tt + r of quad g <-> key 16 tt + 4g + r
+            // the shift tile is private to the wave: LDS operations of one wave execute in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float tmax = -INFINITY;
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
-            const T *vr = vbase + (size_t)(16 * d + il) * Tp + j0 + 4 * g;
-            frag_t va;
-            if constexpr (sizeof(T) == 2) {
-                const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(vr), hi = *reinterpret_cast<const bf16x4 *>(vr + 16);
+                for (int r = 0; r < 4; ++r) {
+                    const int jl = 16 * tt + 4 * g + r;
+                    float s = (sc[tt][r] + sk[(15 - il + jl) * SK + il]) * scale;
+                    s = (js + jl < Tn) ? s : -INFINITY;          // keys of the padded tail of the last tile
+                    sc[tt][r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next sub-tile overwrites the shift tile
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);               // finite: key js is valid
+            const float alpha = __expf(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.f;
+            frag_t pb;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { va[r] = lo[r]; va[4 + r] = hi[r]; }
-            } else {
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(vr), hi = *reinterpret_cast<const f32x4 *>(vr + 16);
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { va[r] = lo[r]; va[4 + r] = hi[r]; }
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(sc[tt][r] - m_new);
+                    psum += p;
+                    pb[4 * tt + r] = from_f32<T>(p);
+                }
+            l_run = l_run * alpha + psum;
+            // ---- O^T = alpha O^T + V^T_sub . P^T
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+                o[d] = mma16(load_vt_frag(vs, RS, 32 * s2, d, il, g, T()), pb, o[d]);
             }
-            o[d] = mma16(va, pb, o[d]);
         }
     }
     // ---- normalise and store: lane holds head dims 16 d + 4g + r of query i0 + il
@@ -145,11 +204,21 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     if (i0 + il < Tn) {
         T *dst = ctx + ((size_t)b * Tn + i0 + il) * (heads * dh) + hh * dh;
 #pragma unroll
-        for (int d = 0; d < DT; ++d)
+        for (int d = 0; d < DT; ++d) {
+            const int dd = 16 * d + 4 * g;
+            if (dd + 3 < dh && (dh & 3) == 0) {
+                float r4[4] = {o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
+                if constexpr (sizeof(T) == 2) { bf16x4 w = {(T)r4[0], (T)r4[1], (T)r4[2], (T)r4[3]}; *reinterpret_cast<bf16x4 *>(dst + dd) = w; }
+                else { *reinterpret_cast<f32x4 *>(dst + dd) = (f32x4){r4[0], r4[1], r4[2], r4[3]}; }
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int dd = 16 * d + 4 * g + r;
-                if (dd < dh) dst[dd] = from_f32<T>(o[d][r] * inv);
+                for (int r = 0; r < 4; ++r)
+                    if (dd + r < dh) dst[dd + r] = from_f32<T>(o[d][r] * inv);
             }
+        }
     }
+}
+
+template <typename T, int DHP> static inline size_t attention_lds_bytes() {
+    return (size_t)(64 + 64 + 128) * (DHP * sizeof(T) + 16) + 4 * 48 * 20 * sizeof(float);
 }

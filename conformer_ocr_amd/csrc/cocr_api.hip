@@ -132,7 +132,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     if (snum < 2) return fail(COCR_EUNSUPPORTED, "subsampling_factor 2 is not covered by the fused frontend kernel");
     if (hp->encoder_dim % 16) return fail(COCR_EUNSUPPORTED, "encoder_dim must be a multiple of 16 (GLU tile pairing, 16-byte rows)");
     if (hp->subsampling_conv_channels % 8) return fail(COCR_EUNSUPPORTED, "subsampling_conv_channels must be a multiple of 8");
-    if (hp->encoder_dim > 64 * COCR_LN_MAX_PER_LANE) return fail(COCR_EUNSUPPORTED, "encoder_dim > 1024");
+    if (hp->encoder_dim > COCR_LN_MAX_D) return fail(COCR_EUNSUPPORTED, "encoder_dim > 1024");
     const int dh = hp->encoder_dim / hp->num_attention_heads;
     if (dh > 128) return fail(COCR_EUNSUPPORTED, "d_head > 128");
     cocr_model *m = new cocr_model();
@@ -456,8 +456,7 @@ template <typename T> static int compute_pos_tables(cocr_model *m, const std::ve
     for (int l = 0; l < m->L; ++l) {
         HIP_TRY(hipMemcpy(d_w, wpos[l]->data.data(), (size_t)D * D * 4, hipMemcpyHostToDevice));
         EpiPosTable<T> epi{(T *)(m->blob + m->plan.layers[l].ptab), m->dh, m->dhp, m->heads};
-        launch_gemm<float>(0, d_pe, D, d_w, D, R, D, D, epi);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_gemm<float>(0, d_pe, D, d_w, D, R, D, D, epi));
         HIP_TRY(hipDeviceSynchronize());
     }
     HIP_TRY(hipFree(d_pe));
@@ -583,6 +582,23 @@ extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, d
 // ------------------------------------------------------------------------------------ forward
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
+#define GEMM_TRY(call)                                                                                 \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(COCR_EHIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T, int DHP>
+static hipError_t launch_attention(hipStream_t s, dim3 grid, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
+                                   const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale) {
+    const size_t lds = attention_lds_bytes<T, DHP>();
+    auto kern = relpos_attention_kernel<T, DHP>;
+    hipError_t e = raise_lds_limit((const void *)kern, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh, scale);
+    return hipGetLastError();
+}
+
 template <typename T, typename TIn>
 static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, float *logits, hipStream_t s) {
     const BlobPlan &P = m->plan;
@@ -606,9 +622,8 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     if ((rc = tap<T>(m, s, "front.z2", za, (size_t)N * T2 * F2 * C))) return rc;
     {
         ProfScope ps(m, s, FAM_FPW);
-        EpiBiasAct<T, ACT_RELU> epi{zb, C, F32(P.stages[0].pw_b)};
-        launch_gemm<T>(s, za, C, WT(P.stages[0].pw_w), C, N * T2 * F2, C, C, epi);
-        LAUNCH_CHECK();
+        EpiBiasAct<T, ACT_RELU> epi{zb, C, F32(P.stages[0].pw_b), C};
+        GEMM_TRY(launch_gemm<T>(s, za, C, WT(P.stages[0].pw_w), C, N * T2 * F2, C, C, epi));
     }
     if ((rc = tap<T>(m, s, "front.z3", zb, (size_t)N * T2 * F2 * C))) return rc;
     int Tc = T2, Fc = F2;
@@ -623,40 +638,39 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         }
         {
             ProfScope ps(m, s, FAM_FPW);
-            EpiBiasAct<T, ACT_RELU> epi{zcur, C, F32(P.stages[st].pw_b)};
-            launch_gemm<T>(s, zoth, C, WT(P.stages[st].pw_w), C, N * To * Fo, C, C, epi);
-            LAUNCH_CHECK();
+            EpiBiasAct<T, ACT_RELU> epi{zcur, C, F32(P.stages[st].pw_b), C};
+            GEMM_TRY(launch_gemm<T>(s, zoth, C, WT(P.stages[st].pw_w), C, N * To * Fo, C, C, epi));
         }
         Tc = To; Fc = Fo;
     }
     const int Tn = Tc, F = Fc, M = N * Tn, Tp = round_up(Tn, 32);
+    float *x = m->x;
     {   // flatten (b,t,(f,c)) is a view of the channel-last tensor; output linear writes the fp32 residual stream
         ProfScope ps(m, s, FAM_FOUT);
-        EpiStoreF32 epi{m->x, D, F32(P.bout)};
-        launch_gemm<T>(s, zcur, F * C, WT(P.wout), F * C, M, D, F * C, epi);
-        LAUNCH_CHECK();
+        EpiStoreF32 epi{x, D, F32(P.bout), D};
+        GEMM_TRY(launch_gemm<T>(s, zcur, F * C, WT(P.wout), F * C, M, D, F * C, epi));
     }
-    if ((rc = tap<float>(m, s, "front.y", m->x, (size_t)M * D))) return rc;
+    if ((rc = tap<float>(m, s, "front.y", x, (size_t)M * D))) return rc;
 
-    T *xn = (T *)m->xn, *hid = (T *)m->hid, *q = (T *)m->q, *k = (T *)m->k, *vt = (T *)m->vt, *ctx = (T *)m->ctx, *glu = (T *)m->glu,
+    T *xn = (T *)m->xn, *hid = (T *)m->hid, *q = (T *)m->q, *k = (T *)m->k, *v = (T *)m->vt, *ctx = (T *)m->ctx, *glu = (T *)m->glu,
       *dwo = (T *)m->dwo;
-    if (m->vtN != N || m->vtT != Tn) {   // pad rows / pad dims of q, k, vt must read as zero for this shape
+    if (m->vtN != N || m->vtT != Tn) {   // pad dims of q, k, v must read as zero for this shape
         HIP_TRY(hipMemsetAsync(q, 0, m->qkv_bytes, s));
         HIP_TRY(hipMemsetAsync(k, 0, m->qkv_bytes, s));
-        HIP_TRY(hipMemsetAsync(vt, 0, m->qkv_bytes, s));
+        HIP_TRY(hipMemsetAsync(v, 0, m->qkv_bytes, s));
         m->vtN = N; m->vtT = Tn;
     }
     const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
     const float scale = 1.0f / sqrtf((float)dh);
     char nm[64];
     auto ffn = [&](const FfnW &w) -> int {
-        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.b1)}; launch_gemm<T>(s, xn, D, WT(w.w1), D, M, ff, D, e); LAUNCH_CHECK(); }
-        { ProfScope ps(m, s, FAM_FFN_DOWN); EpiResidual e{m->x, D, F32(w.b2), ffr}; launch_gemm<T>(s, hid, ff, WT(w.w2), ff, M, D, ff, e); LAUNCH_CHECK(); }
+        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.w1), D, M, ff, D, e)); }
+        { ProfScope ps(m, s, FAM_FFN_DOWN); EpiResidual e{x, D, F32(w.b2), ffr, D}; GEMM_TRY(launch_gemm<T>(s, hid, ff, WT(w.w2), ff, M, D, ff, e)); }
         return COCR_OK;
     };
     auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
         ProfScope ps(m, s, FAM_LN);
-        launch_layernorm<T>(s, m->x, M, D, F32(g1), F32(b1), write_f32 ? m->x : nullptr, g2 >= 0 ? F32((size_t)g2) : nullptr,
+        launch_layernorm<T>(s, x, M, D, F32(g1), F32(b1), write_f32 ? x : nullptr, g2 >= 0 ? F32((size_t)g2) : nullptr,
                             b2 >= 0 ? F32((size_t)b2) : nullptr, xn);
         LAUNCH_CHECK();
         return COCR_OK;
@@ -666,29 +680,28 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         if (l == 0 && (rc = ln(w.ffn[0].ln_g, w.ffn[0].ln_b, false, -1, -1))) return rc;
         // FFN, half-step residual (feed_forward.py:45-52, encoder.py:68-75)
         if ((rc = ffn(w.ffn[0]))) return rc;
-        snprintf(nm, sizeof nm, "l%d.ffn1", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        snprintf(nm, sizeof nm, "l%d.ffn1", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // MHSA (attention.py:143-151)
         if ((rc = ln(w.a_ln_g, w.a_ln_b, false, -1, -1))) return rc;
-        { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, vt, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp}; launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e); LAUNCH_CHECK(); }
+        { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_ATTN);
             dim3 grid(ceil_div(Tn, 64), N * heads);
-#define ATTN(DHP) hipLaunchKernelGGL((relpos_attention_kernel<T, DHP>), grid, dim3(256), 0, s, q, k, vt, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
             if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
-            LAUNCH_CHECK();
         }
         if (m->debug) {
             snprintf(nm, sizeof nm, "l%d.q", l); if ((rc = tap<T>(m, s, nm, q, m->qkv_bytes / sizeof(T)))) return rc;
             snprintf(nm, sizeof nm, "l%d.k", l); if ((rc = tap<T>(m, s, nm, k, m->qkv_bytes / sizeof(T)))) return rc;
-            snprintf(nm, sizeof nm, "l%d.vt", l); if ((rc = tap<T>(m, s, nm, vt, m->qkv_bytes / sizeof(T)))) return rc;
+            snprintf(nm, sizeof nm, "l%d.v", l); if ((rc = tap<T>(m, s, nm, v, m->qkv_bytes / sizeof(T)))) return rc;
             snprintf(nm, sizeof nm, "l%d.ctx", l); if ((rc = tap<T>(m, s, nm, ctx, (size_t)M * D))) return rc;
         }
-        { ProfScope ps(m, s, FAM_AOUT); EpiResidual e{m->x, D, F32(w.bo), 1.0f}; launch_gemm<T>(s, ctx, D, WT(w.wo), D, M, D, D, e); LAUNCH_CHECK(); }
-        snprintf(nm, sizeof nm, "l%d.mhsa", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        { ProfScope ps(m, s, FAM_AOUT); EpiResidual e{x, D, F32(w.bo), 1.0f, D}; GEMM_TRY(launch_gemm<T>(s, ctx, D, WT(w.wo), D, M, D, D, e)); }
+        snprintf(nm, sizeof nm, "l%d.mhsa", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // conv module (convolution.py:135-148)
         if ((rc = ln(w.c_ln_g, w.c_ln_b, false, -1, -1))) return rc;
-        { ProfScope ps(m, s, FAM_GLU); EpiGLU<T> e{glu, D, F32(w.bpw1)}; launch_gemm<T>(s, xn, D, WT(w.wpw1), D, M, 2 * D, D, e); LAUNCH_CHECK(); }
+        { ProfScope ps(m, s, FAM_GLU); EpiGLU<T> e{glu, D, F32(w.bpw1), 2 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wpw1), D, M, 2 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_DW);
             constexpr int TT = 16;
@@ -701,12 +714,12 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             snprintf(nm, sizeof nm, "l%d.glu", l); if ((rc = tap<T>(m, s, nm, glu, (size_t)M * D))) return rc;
             snprintf(nm, sizeof nm, "l%d.dw", l); if ((rc = tap<T>(m, s, nm, dwo, (size_t)M * D))) return rc;
         }
-        { ProfScope ps(m, s, FAM_PW2); EpiResidual e{m->x, D, F32(w.bpw2), 1.0f}; launch_gemm<T>(s, dwo, D, WT(w.wpw2), D, M, D, D, e); LAUNCH_CHECK(); }
-        snprintf(nm, sizeof nm, "l%d.conv", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        { ProfScope ps(m, s, FAM_PW2); EpiResidual e{x, D, F32(w.bpw2), 1.0f, D}; GEMM_TRY(launch_gemm<T>(s, dwo, D, WT(w.wpw2), D, M, D, D, e)); }
+        snprintf(nm, sizeof nm, "l%d.conv", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // second FFN
         if ((rc = ln(w.ffn[1].ln_g, w.ffn[1].ln_b, false, -1, -1))) return rc;
         if ((rc = ffn(w.ffn[1]))) return rc;
-        snprintf(nm, sizeof nm, "l%d.ffn2", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        snprintf(nm, sizeof nm, "l%d.ffn2", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // block-final LayerNorm (encoder.py:99), chained with the next block's first LayerNorm
         if (l + 1 < m->L) {
             const LayerW &nx = P.layers[l + 1];
@@ -714,13 +727,12 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         } else {
             if ((rc = ln(w.f_ln_g, w.f_ln_b, m->debug, -1, -1))) return rc;
         }
-        snprintf(nm, sizeof nm, "l%d.out", l); if ((rc = tap<float>(m, s, nm, m->x, (size_t)M * D))) return rc;
+        snprintf(nm, sizeof nm, "l%d.out", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
     }
     {   // decoder nn.Linear (pred.py:90,121): logits fp32
         ProfScope ps(m, s, FAM_DEC);
-        EpiStoreF32 e{logits, m->ncls, F32(P.bdec)};
-        launch_gemm<T>(s, xn, D, WT(P.wdec), D, M, m->ncls, D, e);
-        LAUNCH_CHECK();
+        EpiStoreF32 e{logits, m->ncls, F32(P.bdec), m->ncls};
+        GEMM_TRY(launch_gemm<T>(s, xn, D, WT(P.wdec), D, M, m->ncls, D, e));
     }
     return COCR_OK;
 }
@@ -784,4 +796,76 @@ extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T,
 extern "C" int cocr_ctc_beam(cocr_model *, const float *, int, int, int, const int32_t *, int32_t *, int32_t *, int32_t *, float *, int32_t *,
                              int, int, void *) {
     return fail(COCR_EUNSUPPORTED, "cocr_ctc_beam: not built yet");
+}
+
+// ------------------------------------------------------------------------------------ kernel micro-benchmarks (development hook)
+__global__ void fill_kernel(unsigned short *p, size_t n, unsigned seed, int as_f32) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const float v = ((float)(h & 0xffff) / 65536.0f - 0.5f);
+        if (as_f32) ((float *)p)[i] = v; else ((bf16_t *)p)[i] = (bf16_t)v;
+    }
+}
+
+struct EpiNull {   // ablation: keeps the accumulators alive, stores (almost) nothing
+    typedef float stage_t;
+    static constexpr bool GLU = false;
+    float *sink;
+    __device__ __forceinline__ void transform(int n, const float *v, float *r) const { for (int i = 0; i < 4; ++i) r[i] = v[i]; }
+    __device__ __forceinline__ void store(int m, int c, const float *src, int cnt) const { if (src[0] == 123.456f) sink[0] = 1.0f; }
+};
+
+// Times one GEMM variant on random operands: returns the average device time per launch in microseconds.
+extern "C" int cocr_dev_bench_gemm(int variant, int M, int N, int K, int iters, double *us_out) {
+    typedef bf16_t T;
+    void *A = nullptr, *W = nullptr, *O = nullptr;
+    float *X = nullptr, *bias = nullptr, *gam = nullptr;
+    HIP_TRY(hipMalloc(&A, (size_t)M * K * 2)); HIP_TRY(hipMalloc(&W, (size_t)N * K * 2)); HIP_TRY(hipMalloc(&O, (size_t)M * N * 4));
+    HIP_TRY(hipMalloc((void **)&X, (size_t)M * K * 4)); HIP_TRY(hipMalloc((void **)&bias, (size_t)N * 4)); HIP_TRY(hipMalloc((void **)&gam, (size_t)K * 4));
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (unsigned short *)A, (size_t)M * K, 1u, 0);
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (unsigned short *)W, (size_t)N * K, 2u, 0);
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (unsigned short *)X, (size_t)M * K, 3u, 1);
+    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, (unsigned short *)bias, (size_t)N, 4u, 1);
+    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, (unsigned short *)gam, (size_t)K, 5u, 1);
+    HIP_TRY(hipMemset(O, 0, (size_t)M * N * 4));
+    GemmArgs<T> a{(const T *)A, K, (const T *)W, K, M, N, K};
+    EpiBiasAct<T, ACT_SILU> eh{(T *)O, N, bias, N};
+    EpiResidual er{(float *)O, N, bias, 0.5f, N};
+    EpiNull en{(float *)O};
+    const bool resid = N <= 256;
+    auto run = [&]() -> hipError_t {
+#define RING(BM, BN, NST) (resid ? launch_ring_cfg<T, BM, BN, NST>(0, a, er) : launch_ring_cfg<T, BM, BN, NST>(0, a, eh))
+        switch (variant) {
+            case 0: return resid ? launch_gemm<T>(0, a.A, K, a.W, K, M, N, K, er) : launch_gemm<T>(0, a.A, K, a.W, K, M, N, K, eh);
+            case 1: return RING(64, 64, 3);
+            case 2: return RING(64, 64, 4);
+            case 3: return RING(64, 128, 3);
+            case 4: return RING(128, 128, 2);
+            case 5: return RING(128, 128, 3);
+            case 6: return RING(128, 64, 3);
+            case 7: return RING(64, 128, 2);
+            case 8: return RING(64, 64, 2);
+            case 9: return resid ? launch_stream_cfg<T, 64, 64>(0, a, er) : launch_stream_cfg<T, 64, 64>(0, a, eh);
+            case 30: return launch_ring_cfg<T, 128, 128, 2>(0, a, en);
+            case 31: return launch_ring_cfg<T, 64, 64, 3>(0, a, en);
+            case 20: launch_layernorm<T>(0, X, M, K, gam, gam, nullptr, nullptr, nullptr, (T *)A); return hipGetLastError();
+            case 21: launch_layernorm<T>(0, X, M, K, gam, gam, X, gam, gam, (T *)A); return hipGetLastError();
+            default: return hipErrorInvalidValue;
+        }
+#undef RING
+    };
+    for (int i = 0; i < 3; ++i) HIP_TRY(run());
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) HIP_TRY(run());
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *us_out = (double)ms * 1e3 / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(O); (void)hipFree(X); (void)hipFree(bias); (void)hipFree(gam);
+    return COCR_OK;
 }

@@ -5,134 +5,278 @@
 // the decoder (pred.py:90).  Both operands are k-contiguous, which is the MFMA fragment order
 // (common.hip.h), so activations (M,K) and nn.Linear weights (N,K) are used as stored.
 //
-// Tile BMxBN per 256-thread workgroup (4 waves as 2x2), k-tile = 128 bytes per row, operands staged
-// global -> registers -> LDS (rows padded by 16 B against ds_read_b128 bank conflicts), two LDS
-// buffers, one barrier per k-tile: the next tile's global loads are in flight during the MFMAs.
+// Two kernels share one epilogue:
+//   gemm_ring_kernel   K % BK == 0.  Operand tiles go global -> LDS by LDS-DMA (global_load_lds, 16 B per
+//                      lane, no VGPR staging) into an NST-deep ring; the k-loop waits with a COUNTED vmcnt so
+//                      NST-1 tiles stay in flight across the raw barrier (one barrier per k-tile).  The LDS
+//                      image is lane-linear (one DMA wave-instruction = 1 KiB = 8 rows of 128 B); the
+//                      bank-conflict swizzle sits on the per-lane SOURCE address and is undone at the fragment
+//                      read: LDS chunk position p of row r holds global chunk p ^ (r & 7).
+//   gemm_stream_kernel any K % (16/sizeof(T)) == 0.  Register-staged tiles (zero-filled k tail), two buffers.
+// Both: 256 threads = 4 waves as 2x2 over a BMxBN tile; k-tile = 128 bytes per row; XCD-aware tile order;
+// MFMA issued with the operands swapped (weights on the row side) so that a lane holds 4 consecutive output
+// columns of one row; the epilogue applies bias / activation / GLU in registers, stages the tile in LDS and
+// writes FULL ROWS, 16 bytes per lane, consecutive lanes consecutive addresses.  (Measured on MI355X: the
+// direct 8-byte-per-lane store of the accumulator layout -- 32-byte row fragments -- took 2/3 of the kernel.)
 #pragma once
+#include <algorithm>
+#include <set>
+
 #include "common.hip.h"
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
-// ---- epilogues: called once per valid output element (m < M, n < N) with the fp32 accumulator ----
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef __attribute__((address_space(1))) const void *gbl_ptr_t;
 
-// out[m, n] = act(acc + bias[n]) stored as T (hidden activations)
+// XCD-aware workgroup remap (8 XCDs, private L2 each; workgroups are dealt round-robin, so ids b and b+8
+// share an XCD).  Logical tile L = chunk(b % 8) + b / 8 gives every XCD a CONTIGUOUS run of logical tiles:
+// all column tiles of a row block then read that row block's A rows through ONE L2 instead of eight.
+// Bijective for any grid size (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- epilogues -------------------------------------------------------------------------------------------
+// stage_t            element type of the LDS-staged tile (compute dtype or float)
+// transform(n, v, r) 4 accumulator columns n..n+3 (n % 4 == 0) -> 4 staged values; GLU: (n, value, gate, r)
+// store(m, c, src, cnt)  `cnt` staged values of row m starting at staged column c (c % CH == 0, CH = 16/sizeof
+//                    (stage_t)); src points into LDS, 16-byte aligned; cnt == CH except at the right edge.
+template <typename U> __device__ __forceinline__ void copy16(U *dst, const U *src) {
+    *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+}
+
+// out[m, n] = act(acc + bias[n]) in the compute dtype (hidden activations)
 template <typename T, int ACT> struct EpiBiasAct {
-    static constexpr bool PAIRED = false;
-    T *out; int ldo; const float *bias;
-    __device__ __forceinline__ void operator()(int m, int n, float v) const {
-        v += bias[n];
-        if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
-        if (ACT == ACT_SILU) v = silu_f(v);
-        out[(size_t)m * ldo + n] = from_f32<T>(v);
+    typedef T stage_t;
+    static constexpr bool GLU = false;
+    T *out; int ldo; const float *bias; int N;
+    __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = v[i] + (n + i < N ? bias[n + i] : 0.f);
+            if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
+            if (ACT == ACT_SILU) x = silu_f(x);
+            r[i] = x;
+        }
+    }
+    __device__ __forceinline__ void store(int m, int c, const T *src, int cnt) const {
+        T *p = out + (size_t)m * ldo + c;
+        if (cnt == 16 / (int)sizeof(T) && (ldo % (16 / (int)sizeof(T))) == 0) copy16(p, src);
+        else for (int i = 0; i < cnt; ++i) p[i] = src[i];
     }
 };
 
-// out[m, n] = acc (+ bias[n]) as fp32 (frontend output = residual stream; decoder logits)
+// out[m, n] = acc + bias[n] as fp32 (frontend output = residual stream; decoder logits)
 struct EpiStoreF32 {
-    static constexpr bool PAIRED = false;
-    float *out; int ldo; const float *bias;
-    __device__ __forceinline__ void operator()(int m, int n, float v) const {
-        out[(size_t)m * ldo + n] = bias ? v + bias[n] : v;
+    typedef float stage_t;
+    static constexpr bool GLU = false;
+    float *out; int ldo; const float *bias; int N;
+    __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = v[i] + (n + i < N ? bias[n + i] : 0.f);
+    }
+    __device__ __forceinline__ void store(int m, int c, const float *src, int cnt) const {
+        float *p = out + (size_t)m * ldo + c;
+        if (cnt == 4 && (ldo & 3) == 0) copy16(p, src);
+        else for (int i = 0; i < cnt; ++i) p[i] = src[i];
     }
 };
 
 // x[m, n] += alpha * (acc + bias[n])  -- ResidualConnectionModule, modules.py:32 (input_factor 1)
 struct EpiResidual {
-    static constexpr bool PAIRED = false;
-    float *x; int ldx; const float *bias; float alpha;
-    __device__ __forceinline__ void operator()(int m, int n, float v) const {
-        float *p = x + (size_t)m * ldx + n;
-        *p = *p + alpha * (v + bias[n]);
+    typedef float stage_t;
+    static constexpr bool GLU = false;
+    float *x; int ldx; const float *bias; float alpha; int N;
+    __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = alpha * (v[i] + (n + i < N ? bias[n + i] : 0.f));
+    }
+    __device__ __forceinline__ void store(int m, int c, const float *src, int cnt) const {
+        float *p = x + (size_t)m * ldx + c;
+        if (cnt == 4 && (ldx & 3) == 0) {
+            f32x4 o = *reinterpret_cast<f32x4 *>(p);
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(src);
+            o += d;
+            *reinterpret_cast<f32x4 *>(p) = o;
+        } else {
+            for (int i = 0; i < cnt; ++i) p[i] += src[i];
+        }
     }
 };
 
 // GLU over channels (convolution.py:139): the weight rows are interleaved at load time so that the
-// 16-column tile 2j holds the value half of channels 16j..16j+15 and tile 2j+1 their gates;
-// out[m, 16j + c] = (a + ba) * sigmoid(g + bg)
+// 16-column tile 2j holds the value half of channels 16j..16j+15 and tile 2j+1 their gates:
+// out[m, 16j + c] = (a + ba) * sigmoid(g + bg).  N (= 2D) is a multiple of 32.
 template <typename T> struct EpiGLU {
-    static constexpr bool PAIRED = true;
-    T *out; int ldo; const float *bias;
-    __device__ __forceinline__ void operator()(int m, int n, float a, float g) const {
-        a += bias[n];
-        g += bias[n + 16];
-        const int ch = ((n >> 5) << 4) + (n & 15);
-        out[(size_t)m * ldo + ch] = from_f32<T>(a * sigmoid_f(g));
+    typedef T stage_t;
+    static constexpr bool GLU = true;
+    T *out; int ldo; const float *bias; int N;
+    __device__ __forceinline__ void transform(int n, const float *v, const float *gte, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = (v[i] + bias[n + i]) * sigmoid_f(gte[i] + bias[n + 16 + i]);
+    }
+    __device__ __forceinline__ void store(int m, int c, const T *src, int cnt) const {
+        T *p = out + (size_t)m * ldo + c;
+        if (cnt == 16 / (int)sizeof(T)) copy16(p, src);
+        else for (int i = 0; i < cnt; ++i) p[i] = src[i];
     }
 };
 
-// fused q/k/v projection (N = 3D): scatter into the attention layouts
-//   q, k : [B][h][Tp][dhp]   (head dim padded to a multiple of 32 with zeros, rows >= T unused)
-//   vt   : [B][h][dhp][Tp]   (V transposed: keys contiguous, the B-operand order of P.V)
+// fused q/k/v projection (N = 3D): rows scattered into the attention layout [B][h][Tp][dhp] of q, k, v
+// (head dim padded to a multiple of 32 with zeros; rows >= T unused).
 template <typename T> struct EpiQKV {
-    static constexpr bool PAIRED = false;
-    T *q, *k, *vt; const float *bias; int D, dh, dhp, heads, T_, Tp;
-    __device__ __forceinline__ void operator()(int m, int n, float v) const {
-        v += bias[n];
-        const int which = n / D, hd = n - which * D;
-        const int hh = hd / dh, d = hd - hh * dh;
+    typedef T stage_t;
+    static constexpr bool GLU = false;
+    T *q, *k, *v; const float *bias; int D, dh, dhp, heads, T_, Tp, N;
+    __device__ __forceinline__ void transform(int n, const float *a, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = a[i] + (n + i < N ? bias[n + i] : 0.f);
+    }
+    __device__ __forceinline__ T *dst(int b, int t, int n) const {
+        const int which = n / D, hd = n - which * D, hh = hd / dh, d = hd - hh * dh;
+        T *base = which == 0 ? q : (which == 1 ? k : v);
+        return base + (((size_t)b * heads + hh) * Tp + t) * dhp + d;
+    }
+    __device__ __forceinline__ void store(int m, int c, const T *src, int cnt) const {
         const int b = m / T_, t = m - b * T_;
-        const size_t bh = (size_t)b * heads + hh;
-        if (which == 2) vt[(bh * dhp + d) * Tp + t] = from_f32<T>(v);
-        else (which == 0 ? q : k)[(bh * Tp + t) * dhp + d] = from_f32<T>(v);
+        constexpr int CH = 16 / (int)sizeof(T);
+        if (cnt == CH && (dh % CH) == 0 && (D % CH) == 0) copy16(dst(b, t, c), src);   // the chunk stays inside one head
+        else for (int i = 0; i < cnt; ++i) *dst(b, t, c + i) = src[i];
     }
 };
 
 // positional projection table P = PE Wpos^T into [row][h][dhp] (head-padded)
 template <typename T> struct EpiPosTable {
-    static constexpr bool PAIRED = false;
+    typedef T stage_t;
+    static constexpr bool GLU = false;
     T *out; int dh, dhp, heads;
-    __device__ __forceinline__ void operator()(int m, int n, float v) const {
-        const int hh = n / dh, d = n - hh * dh;
-        out[((size_t)m * heads + hh) * dhp + d] = from_f32<T>(v);
+    __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = v[i];
+    }
+    __device__ __forceinline__ void store(int m, int c, const T *src, int cnt) const {
+        for (int i = 0; i < cnt; ++i) {
+            const int hh = (c + i) / dh, d = (c + i) - hh * dh;
+            out[((size_t)m * heads + hh) * dhp + d] = src[i];
+        }
     }
 };
 
-// ---- kernel -----------------------------------------------------------------------------------
+template <typename S> __device__ __forceinline__ void stage4(S *dst, const float *r);
+template <> __device__ __forceinline__ void stage4<float>(float *dst, const float *r) { *reinterpret_cast<f32x4 *>(dst) = (f32x4){r[0], r[1], r[2], r[3]}; }
+template <> __device__ __forceinline__ void stage4<bf16_t>(bf16_t *dst, const float *r) {
+    bf16x4 o = {(bf16_t)r[0], (bf16_t)r[1], (bf16_t)r[2], (bf16_t)r[3]};
+    *reinterpret_cast<bf16x4 *>(dst) = o;
+}
 
-template <typename T, int BM, int BN, typename Epi>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const T *__restrict__ A, int lda, const T *__restrict__ W, int ldw,
-                                                      int M, int N, int K, Epi epi) {
-    constexpr int ROWB = 128;               // bytes of k per row per tile
-    constexpr int BK = ROWB / sizeof(T);    // bf16: 64, fp32: 32
-    constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
-    constexpr int STRIDE = ROWB + 16;       // padded LDS row
+// bytes of LDS the staged epilogue needs
+template <typename Epi, int BM, int BN> constexpr size_t epi_lds_bytes() {
+    return (size_t)BM * ((Epi::GLU ? BN / 2 : BN) * sizeof(typename Epi::stage_t) + 16);
+}
+
+// Accumulator (i, j), reg q of a wave = element (m = 16 i + r16, n = 16 j + 4 g + q) of the wave's (BM/2)x(BN/2)
+// quadrant.  Must be entered by all 256 threads after the last LDS read of the k-loop has been fenced by a barrier.
+template <int BM, int BN, int MI, int NI, typename Epi>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], unsigned char *smem, int m0, int n0, int M, int N, const Epi &epi) {
+    typedef typename Epi::stage_t S;
+    constexpr int COLS = Epi::GLU ? BN / 2 : BN;
+    constexpr int RS = COLS * (int)sizeof(S) + 16;          // staged row stride, bytes
+    constexpr int CH = 16 / (int)sizeof(S);                 // elements per 16-byte chunk
+    constexpr int CPR = COLS / CH;                          // chunks per staged row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * (BM / 2) + 16 * i + r16;
+        if constexpr (Epi::GLU) {
+#pragma unroll
+            for (int j = 0; j < NI; j += 2) {
+                const int nl = wn * (BN / 2) + 16 * j + 4 * g;          // local column of the value tile
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const float w[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                if (n0 + nl + 19 < N) epi.transform(n0 + nl, v, w, r);
+                stage4<S>(reinterpret_cast<S *>(smem + row * RS) + ((nl >> 5) << 4) + (nl & 15), r);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nl = wn * (BN / 2) + 16 * j + 4 * g;
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float r[4];
+                epi.transform(n0 + nl, v, r);
+                stage4<S>(reinterpret_cast<S *>(smem + row * RS) + nl, r);
+            }
+        }
+    }
+    __syncthreads();
+    const int c0 = Epi::GLU ? n0 / 2 : n0, cend = Epi::GLU ? N / 2 : N;     // staged-column range of this tile in the output
+    for (int id = threadIdx.x; id < BM * CPR; id += 256) {
+        const int row = id / CPR, ch = id - row * CPR;
+        const int m = m0 + row, c = c0 + ch * CH;
+        if (m < M && c < cend) epi.store(m, c, reinterpret_cast<const S *>(smem + row * RS) + ch * CH, min(CH, cend - c));
+    }
+}
+
+// ---- kernel arguments ----------------------------------------------------------------------------
+template <typename T> struct GemmArgs {
+    const T *A; int lda;
+    const T *W; int ldw;
+    int M, N, K;
+};
+
+__device__ __forceinline__ bf16x8 lds_frag_swz(const unsigned char *row, int kc, int g, int swz, bf16_t) {
+    return *reinterpret_cast<const bf16x8 *>(row + (((kc * 4 + g) ^ swz) << 4));
+}
+__device__ __forceinline__ f32x8 lds_frag_swz(const unsigned char *row, int kc, int g, int swz, float) {
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(row + (((2 * g) ^ swz) << 4));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(row + (((2 * g + 1) ^ swz) << 4));
+    return (f32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- LDS-DMA ring kernel (K % BK == 0) --------------------------------------------------------------------
+template <typename T, int BM, int BN, int NST, typename Epi>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) {
+    constexpr int ROWB = 128;
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int EPC = 16 / sizeof(T);
     constexpr int MI = BM / 32, NI = BN / 32;
-    constexpr int A_IT = BM * 8 / 256, W_IT = BN * 8 / 256;
-    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * STRIDE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int PER = BM / 32 + BN / 32;                 // DMA wave-instructions per wave per k-tile
+    constexpr int STAGE = (BM + BN) * ROWB;
+    static_assert(NST >= 2 && NST <= 4 && BM % 32 == 0 && BN % 64 == 0, "config");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = p.M, N = p.N, K = p.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4, swz = r16 & 7;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int gx = (N + BN - 1) / BN;
+    const int ltile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (ltile / gx) * BM, n0 = (ltile % gx) * BN;
+    const int nk = K / BK;
 
-    uint4 ra[A_IT], rw[W_IT];
-    auto load_tile = [&](int k0) {
+    auto issue = [&](int kt) {
+        unsigned char *st = smem + (kt % NST) * STAGE;
+        const int k0 = kt * BK, lrow = lane >> 3, cpos = lane & 7;
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
-            const int m = m0 + row, k = k0 + ch * EPC;
-            ra[it] = (m < M && k < K) ? *reinterpret_cast<const uint4 *>(A + (size_t)m * lda + k) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < BM / 32; ++i) {
+            const int rg = wave + 4 * i, row = rg * 8 + lrow;
+            const T *src = p.A + (size_t)min(m0 + row, M - 1) * p.lda + k0 + ((cpos ^ (row & 7)) * EPC);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + rg * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
-            const int n = n0 + row, k = k0 + ch * EPC;
-            rw[it] = (n < N && k < K) ? *reinterpret_cast<const uint4 *>(W + (size_t)n * ldw + k) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4 *>(&smem[buf][row * STRIDE + ch * 16]) = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4 *>(&smem[buf][(BM + row) * STRIDE + ch * 16]) = rw[it];
+        for (int i = 0; i < BN / 32; ++i) {
+            const int rg = wave + 4 * i, row = rg * 8 + lrow;
+            const T *src = p.W + (size_t)min(n0 + row, N - 1) * p.ldw + k0 + ((cpos ^ (row & 7)) * EPC);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + BM * ROWB + rg * 1024), 16, 0, 0);
         }
     };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) issue(t);
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -140,6 +284,84 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T *__restrict__ A, i
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed: only tiles issued after it may still be in flight
+        const int after = min(nk, kt + NST - 1) - (kt + 1);
+        if (after >= 2) wait_vmcnt<2 * PER>(); else if (after == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nk) issue(kt + NST - 1);       // refills the slot every wave finished reading before this barrier
+        const unsigned char *st = smem + (kt % NST) * STAGE;
+        const unsigned char *sa = st + (wm * (BM / 2) + r16) * ROWB;
+        const unsigned char *sw = st + BM * ROWB + (wn * (BN / 2) + r16) * ROWB;
+#pragma unroll
+        for (int kc = 0; kc < BK / 32; ++kc) {
+            typename FragOf<T>::type a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = lds_frag_swz(sa + i * 16 * ROWB, kc, g, swz, T());
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = lds_frag_swz(sw + j * 16 * ROWB, kc, g, swz, T());
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mma16(b[j], a[i], acc[i][j]);   // swapped: rows = n, columns = m
+        }
+    }
+    __syncthreads();                                     // every wave is done reading the ring: reuse it for the staged tile
+    gemm_epilogue<BM, BN, MI, NI, Epi>(acc, smem, m0, n0, M, N, epi);
+}
+
+// ---- register-staged kernel (any k tail) ---------------------------------------------------------------------
+template <typename T, int BM, int BN, typename Epi>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs<T> p, Epi epi) {
+    constexpr int ROWB = 128;
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int STRIDE = ROWB + 16;
+    constexpr int MI = BM / 32, NI = BN / 32;
+    constexpr int A_IT = BM * 8 / 256, W_IT = BN * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = p.M, N = p.N, K = p.K;
+    const int Kp = (K + 31) & ~31;
+    unsigned char *a_area = smem, *w_area = smem + 2 * BM * STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int gx = (N + BN - 1) / BN;
+    const int ltile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (ltile / gx) * BM, n0 = (ltile % gx) * BN;
+
+    uint4 ra[A_IT], rw[W_IT];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
+            const int m = m0 + row, k = k0 + ch * EPC;
+            ra[it] = (m < M && k < K) ? *reinterpret_cast<const uint4 *>(p.A + (size_t)m * p.lda + k) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
+            const int n = n0 + row, k = k0 + ch * EPC;
+            rw[it] = (n < N && k < K) ? *reinterpret_cast<const uint4 *>(p.W + (size_t)n * p.ldw + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<uint4 *>(a_area + (buf * BM + row) * STRIDE + ch * 16) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<uint4 *>(w_area + (buf * BN + row) * STRIDE + ch * 16) = rw[it];
+        }
+    };
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (K + BK - 1) / BK;
     load_tile(0);
     store_tile(0);
@@ -147,67 +369,69 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T *__restrict__ A, i
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const unsigned char *sa = &smem[buf][(wm * (BM / 2) + r16) * STRIDE];
-        const unsigned char *sw = &smem[buf][(BM + wn * (BN / 2) + r16) * STRIDE];
+        const unsigned char *sa = a_area + (buf * BM + wm * (BM / 2) + r16) * STRIDE;
+        const unsigned char *sw = w_area + (buf * BN + wn * (BN / 2) + r16) * STRIDE;
 #pragma unroll
         for (int kc = 0; kc < BK / 32; ++kc) {
-            const int off = kc * 32 * (int)sizeof(T) + g * 8 * (int)sizeof(T);
-            typename FragOf<T>::type a[MI], b[NI];
+            if (kt * BK + kc * 32 < Kp) {
+                const int off = kc * 32 * (int)sizeof(T) + g * 8 * (int)sizeof(T);
+                typename FragOf<T>::type a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = load_frag(reinterpret_cast<const T *>(sa + i * 16 * STRIDE + off));
+                for (int i = 0; i < MI; ++i) a[i] = load_frag(reinterpret_cast<const T *>(sa + i * 16 * STRIDE + off));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = load_frag(reinterpret_cast<const T *>(sw + j * 16 * STRIDE + off));
+                for (int j = 0; j < NI; ++j) b[j] = load_frag(reinterpret_cast<const T *>(sw + j * 16 * STRIDE + off));
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mma16(b[j], a[i], acc[i][j]);
+            }
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
-
-    // epilogue: accumulator (i, j), reg q is element (row 4g + q, column r16) of its 16x16 tile
-    const int mb = m0 + wm * (BM / 2) + 4 * g, nb = n0 + wn * (BN / 2) + r16;
-    if constexpr (Epi::PAIRED) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; j += 2) {
-                const int n = nb + j * 16;
-                if (n + 16 < N)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int m = mb + i * 16 + q;
-                        if (m < M) epi(m, n, acc[i][j][q], acc[i][j + 1][q]);
-                    }
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = nb + j * 16;
-                if (n < N)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int m = mb + i * 16 + q;
-                        if (m < M) epi(m, n, acc[i][j][q]);
-                    }
-            }
-    }
+    gemm_epilogue<BM, BN, MI, NI, Epi>(acc, smem, m0, n0, M, N, epi);
 }
 
-// Host launcher.  Requirements (checked by the caller at model build): K % (16/sizeof(T)) == 0,
-// lda/ldw multiples of 16 bytes, base pointers 16-byte aligned.
+// ---- host side ---------------------------------------------------------------------------------------
+static inline hipError_t raise_lds_limit(const void *kern, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    static std::set<const void *> raised;      // per kernel instantiation, once
+    if (raised.count(kern)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) raised.insert(kern);
+    return e;
+}
+
+template <typename T, int BM, int BN, int NST, typename Epi>
+static inline hipError_t launch_ring_cfg(hipStream_t s, const GemmArgs<T> &a, const Epi &epi) {
+    const size_t lds = std::max((size_t)NST * (BM + BN) * 128, epi_lds_bytes<Epi, BM, BN>());
+    auto kern = gemm_ring_kernel<T, BM, BN, NST, Epi>;
+    hipError_t e = raise_lds_limit((const void *)kern, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, BN) * ceil_div(a.M, BM)), dim3(256), lds, s, a, epi);
+    return hipGetLastError();
+}
+template <typename T, int BM, int BN, typename Epi>
+static inline hipError_t launch_stream_cfg(hipStream_t s, const GemmArgs<T> &a, const Epi &epi) {
+    const size_t lds = std::max((size_t)2 * (BM + BN) * 144, epi_lds_bytes<Epi, BM, BN>());
+    auto kern = gemm_stream_kernel<T, BM, BN, Epi>;
+    hipError_t e = raise_lds_limit((const void *)kern, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, BN) * ceil_div(a.M, BM)), dim3(256), lds, s, a, epi);
+    return hipGetLastError();
+}
+
+// Requirements (checked at model build): K % (16/sizeof(T)) == 0, lda/ldw multiples of 16 bytes, 16-byte aligned bases.
 template <typename T, typename Epi>
-static inline void launch_gemm(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, const Epi &epi) {
-    // small-N products at M ~ 10^4 would leave most of the 256 CUs idle with 128x128 tiles
-    const long blocks128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    if (blocks128 >= 512) {
-        dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
-        hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, M, N, K, epi);
-    } else {
-        dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
-        hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64, Epi>), grid, dim3(256), 0, s, A, lda, W, ldw, M, N, K, epi);
+static inline hipError_t launch_gemm(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, const Epi &epi) {
+    GemmArgs<T> a{A, lda, W, ldw, M, N, K};
+    constexpr int BK = 128 / (int)sizeof(T);
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    if (K % BK == 0) {
+        if (t128 >= 1024) return launch_ring_cfg<T, 128, 128, 2, Epi>(s, a, epi);
+        if (N >= 512) return launch_ring_cfg<T, 64, 128, 3, Epi>(s, a, epi);
+        return launch_ring_cfg<T, 64, 64, 3, Epi>(s, a, epi);
     }
+    if (t128 >= 1024) return launch_stream_cfg<T, 128, 128, Epi>(s, a, epi);
+    return launch_stream_cfg<T, 64, 64, Epi>(s, a, epi);
 }

@@ -2,86 +2,115 @@
 // nn.LayerNorm that opens each FFN / attention / conv module (reference feed_forward.py:46,
 // attention.py:139,148, convolution.py:136) and closes each block (encoder.py:99).
 //
-// One wave per row, the row held in registers (D <= 1024), two wave-shuffle reductions (mean, then
-// the centred second moment, like torch).  Optional chain: a block's closing LayerNorm writes the
-// fp32 stream back in place and the next module's LayerNorm is applied to that result in the same
-// pass (two LayerNorms back to back with different affine parameters), writing the GEMM operand in
-// the compute dtype.  HBM-bound: algorithmic bytes = one fp32 read (+ one fp32 write if chained)
-// + one T write per element.
+// One wave normalises 4 rows at a time (4 independent load -> reduce -> write chains in flight); a row is
+// D/4 float4 chunks, lane owns chunks lane, lane+64, ... (NV = ceil(D/256)); mean and the centred second
+// moment (like torch) by wave-shuffle reductions.  Optional chain: a block's closing LayerNorm writes the
+// fp32 stream back and the next module's LayerNorm is applied to that result in the same pass (two
+// LayerNorms back to back with different affine parameters), writing the GEMM operand in the compute dtype.
+// HBM-bound: algorithmic bytes = one fp32 read (+ one fp32 write if chained) + one T write per element.
 #pragma once
 #include "common.hip.h"
 
-#define COCR_LN_MAX_PER_LANE 16   // D <= 64 * 16
+#define COCR_LN_MAX_D 1024
 
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int M, int D, float eps,
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int M, int D, float eps,
                                                         const float *__restrict__ g1, const float *__restrict__ b1,
-                                                        float *__restrict__ out_f32,      // nullable: LN1 result, fp32
+                                                        float *out_f32,                    // nullable: LN1 result, fp32 (may alias x)
                                                         const float *__restrict__ g2, const float *__restrict__ b2,  // nullable
-                                                        T *__restrict__ out_t)            // nullable: LN2(LN1) or LN1 as T
+                                                        T *__restrict__ out_t)             // nullable: LN2(LN1) or LN1 as T
 {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float *xr = x + (size_t)row * D;
-    float v[COCR_LN_MAX_PER_LANE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * 4;
+    if (row0 >= M) return;
     const float inv_d = 1.0f / (float)D;
-    float s = 0.f;
+    const int nchunk = D >> 2;
+    f32x4 ga[NV], ba[NV], gb[NV], bb[NV];
 #pragma unroll
-    for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < D ? xr[c] : 0.f;
-        s += v[i];
+    for (int v = 0; v < NV; ++v) {
+        const int c = lane + 64 * v;
+        const bool ok = c < nchunk;
+        ga[v] = ok ? *reinterpret_cast<const f32x4 *>(g1 + 4 * c) : (f32x4){0, 0, 0, 0};
+        ba[v] = ok ? *reinterpret_cast<const f32x4 *>(b1 + 4 * c) : (f32x4){0, 0, 0, 0};
+        if (g2) {
+            gb[v] = ok ? *reinterpret_cast<const f32x4 *>(g2 + 4 * c) : (f32x4){0, 0, 0, 0};
+            bb[v] = ok ? *reinterpret_cast<const f32x4 *>(b2 + 4 * c) : (f32x4){0, 0, 0, 0};
+        }
     }
-    float mean = wave_sum(s) * inv_d;
-    float q = 0.f;
+    f32x4 xv[4][NV];
+    float s[4];
 #pragma unroll
-    for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        const float d = c < D ? v[i] - mean : 0.f;
-        q += d * d;
-    }
-    float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+    for (int r = 0; r < 4; ++r) {
+        const int m = row0 + r;
+        s[r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D) v[i] = (v[i] - mean) * rstd * g1[c] + b1[c];
+        for (int v = 0; v < NV; ++v) {
+            const int c = lane + 64 * v;
+            xv[r][v] = (m < M && c < nchunk) ? *reinterpret_cast<const f32x4 *>(x + (size_t)m * D + 4 * c) : (f32x4){0, 0, 0, 0};
+            s[r] += xv[r][v][0] + xv[r][v][1] + xv[r][v][2] + xv[r][v][3];
+        }
     }
+    auto normalise = [&](const f32x4 *gam, const f32x4 *bet) {
+        float mean[4], q[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mean[r] = wave_sum(s[r]) * inv_d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            q[r] = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const bool ok = lane + 64 * v < nchunk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = ok ? xv[r][v][e] - mean[r] : 0.f; q[r] += d * d; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rstd = 1.0f / sqrtf(wave_sum(q[r]) * inv_d + eps);
+            s[r] = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xv[r][v][e] = (xv[r][v][e] - mean[r]) * rstd * gam[v][e] + bet[v][e];   // chunks beyond D: gamma = beta = 0
+                    s[r] += xv[r][v][e];
+                }
+        }
+    };
+    normalise(ga, ba);
     if (out_f32) {
 #pragma unroll
-        for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) out_f32[(size_t)row * D + c] = v[i];
+        for (int r = 0; r < 4; ++r) {
+            const int m = row0 + r;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = lane + 64 * v;
+                if (m < M && c < nchunk) *reinterpret_cast<f32x4 *>(out_f32 + (size_t)m * D + 4 * c) = xv[r][v];
+            }
         }
     }
     if (!out_t) return;
-    if (g2) {
-        s = 0.f;
+    if (g2) normalise(gb, bb);
 #pragma unroll
-        for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) s += (lane + 64 * i < D) ? v[i] : 0.f;
-        mean = wave_sum(s) * inv_d;
-        q = 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int m = row0 + r;
 #pragma unroll
-        for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) {
-            const float d = (lane + 64 * i < D) ? v[i] - mean : 0.f;
-            q += d * d;
+        for (int v = 0; v < NV; ++v) {
+            const int c = lane + 64 * v;
+            if (m < M && c < nchunk) {
+                T *p = out_t + (size_t)m * D + 4 * c;
+                if constexpr (sizeof(T) == 2) { bf16x4 o = {(T)xv[r][v][0], (T)xv[r][v][1], (T)xv[r][v][2], (T)xv[r][v][3]}; *reinterpret_cast<bf16x4 *>(p) = o; }
+                else { *reinterpret_cast<f32x4 *>(p) = xv[r][v]; }
+            }
         }
-        rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
-#pragma unroll
-        for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) v[i] = (v[i] - mean) * rstd * g2[c] + b2[c];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < COCR_LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D) out_t[(size_t)row * D + c] = from_f32<T>(v[i]);
     }
 }
 
 template <typename T>
 static inline void launch_layernorm(hipStream_t s, const float *x, int M, int D, const float *g1, const float *b1,
                                     float *out_f32, const float *g2, const float *b2, T *out_t) {
-    hipLaunchKernelGGL((layernorm_kernel<T>), dim3(ceil_div(M, 4)), dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
+    dim3 grid(ceil_div(M, 16));
+    if (D <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
+    else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
+    else hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
 }

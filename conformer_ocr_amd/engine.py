@@ -43,6 +43,7 @@ class HipRecognizer:
         _lib.check(self.lib.cocr_create(C.byref(chp), self.dev_index, C.byref(h)))
         self._h = h
         self.ready = False
+        self._pinned = {}
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -121,7 +122,9 @@ class HipRecognizer:
                                              out_lens.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(self.device)))
         return logits, out_lens
 
-    def _decode(self, fn, logits: torch.Tensor, out_lens, extra=()) -> List[List[Tuple[int, int, int, float]]]:
+    def _decode_async(self, fn, logits: torch.Tensor, out_lens, extra=()):
+        """Enqueues the decode kernel and the device->host copy of the compact records on the current stream;
+        returns a handle for `collect` (pinned host buffers + an event)."""
         if logits.device != self.device or logits.dtype != torch.float32:
             raise RuntimeError('logits must be float32 on the model device')
         logits = logits.contiguous()
@@ -134,14 +137,36 @@ class HipRecognizer:
             _lib.check(fn(self._h, C.c_void_p(logits.data_ptr()), N, T, ncls, lens.ctypes.data_as(C.POINTER(C.c_int32)),
                           C.c_void_p(ints[0].data_ptr()), C.c_void_p(ints[1].data_ptr()), C.c_void_p(ints[2].data_ptr()),
                           C.c_void_p(conf.data_ptr()), C.c_void_p(counts.data_ptr()), T, *extra, _stream_ptr(self.device)))
-        ints_h = ints.cpu().numpy()
-        conf_h = conf.cpu().numpy()
-        cnt = counts.cpu().numpy()
+            key = (N, T)
+            pool = self._pinned.setdefault(key, [])
+            host = pool.pop() if pool else (torch.empty((3, N, T), dtype=torch.int32).pin_memory(),
+                                            torch.empty((N, T), dtype=torch.float32).pin_memory(),
+                                            torch.empty((N,), dtype=torch.int32).pin_memory())
+            host[0].copy_(ints, non_blocking=True)
+            host[1].copy_(conf, non_blocking=True)
+            host[2].copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        return (key, host, ev, (ints, conf, counts, logits))
+
+    def collect(self, handle) -> List[List[Tuple[int, int, int, float]]]:
+        """Waits for a `_decode_async` handle and builds the per-line (label, start, end, conf) lists."""
+        key, host, ev, _keep = handle
+        ev.synchronize()
+        ints_h, conf_h, cnt = host[0].numpy(), host[1].numpy(), host[2].numpy()
         out = []
-        for n in range(N):
+        for n in range(key[0]):
             c = int(cnt[n])
-            out.append([(int(ints_h[0, n, i]), int(ints_h[1, n, i]), int(ints_h[2, n, i]), float(conf_h[n, i])) for i in range(c)])
+            lab, st, en, cf = ints_h[0, n, :c].tolist(), ints_h[1, n, :c].tolist(), ints_h[2, n, :c].tolist(), conf_h[n, :c].tolist()
+            out.append(list(zip(lab, st, en, cf)))
+        self._pinned[key].append(host)
         return out
+
+    def _decode(self, fn, logits: torch.Tensor, out_lens, extra=()) -> List[List[Tuple[int, int, int, float]]]:
+        return self.collect(self._decode_async(fn, logits, out_lens, extra))
+
+    def ctc_greedy_async(self, logits: torch.Tensor, out_lens):
+        return self._decode_async(self.lib.cocr_ctc_greedy, logits, out_lens)
 
     def ctc_greedy(self, logits: torch.Tensor, out_lens) -> List[List[Tuple[int, int, int, float]]]:
         return self._decode(self.lib.cocr_ctc_greedy, logits, out_lens)

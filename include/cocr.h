@@ -120,7 +120,7 @@ int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, int ncls, co
                   int max_per_line, int beam, void *stream);
 
 /* Test taps: with debug on, cocr_forward keeps a float32 copy of every stage output
- * ("front.z2", "front.z3", "front.y", "l<i>.ffn1|mhsa|conv|ffn2|out", "l<i>.q|k|vt|ctx|glu|dw").
+ * ("front.z2", "front.z3", "front.y", "l<i>.ffn1|mhsa|conv|ffn2|out", "l<i>.q|k|v|ctx|glu|dw").
  * cocr_debug_tap copies one to HOST memory; *n_elems receives its element count. */
 int cocr_set_debug(cocr_model *m, int on);
 int cocr_debug_tap(cocr_model *m, const char *name, float *host_out, int64_t max_elems, int64_t *n_elems);

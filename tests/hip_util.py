@@ -29,8 +29,6 @@ def oracle_taps(hp, state, image, lens):
     lg, ol = Oracle(hp, state, torch.float32).forward(torch.from_numpy(image), torch.from_numpy(lens), taps)
     out = {k: v.numpy() for k, v in taps.items()}
     # the attention operand layouts of the HIP path
-    for l in range(hp.num_encoder_layers):
-        out[f'l{l}.vt'] = out.pop(f'l{l}.v')
     return lg.numpy(), ol.numpy(), out
 
 
@@ -40,10 +38,8 @@ def hip_tap(eng, name, hp, N, T):
     h, dh = hp.num_attention_heads, hp.d_head
     dhp, Tp = -(-dh // 32) * 32, -(-T // 32) * 32
     kind = name.split('.')[-1]
-    if kind in ('q', 'k'):
+    if kind in ('q', 'k', 'v'):
         return a[:N * h * Tp * dhp].reshape(N, h, Tp, dhp)[:, :, :T, :dh].transpose(0, 2, 1, 3)
-    if kind == 'vt':
-        return a[:N * h * dhp * Tp].reshape(N, h, dhp, Tp)[:, :, :dh, :T].transpose(0, 3, 1, 2)
     if kind in ('z2', 'z3'):
         return a.reshape(N, T, -1, hp.subsampling_conv_channels)
     return a.reshape(N, T, -1)

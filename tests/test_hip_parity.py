@@ -43,7 +43,7 @@ def test_tiny_stage_taps(case, dtype, tol):
         if k.startswith('tap:'):
             worst[k[4:]] = float(np.abs(hip_tap(eng, k[4:], hp, N, T) - g[k]).max())
     for l in range(hp.num_encoder_layers):      # operand-level taps exist only in the oracle
-        for nm in ('q', 'k', 'vt', 'ctx', 'glu', 'dw'):
+        for nm in ('q', 'k', 'v', 'ctx', 'glu', 'dw'):
             worst[f'l{l}.{nm}(oracle)'] = float(np.abs(hip_tap(eng, f'l{l}.{nm}', hp, N, T) - otaps[f'l{l}.{nm}']).max())
     worst['logits'] = float(np.abs(logits - g['logits']).max())
     _log(f'tiny_taps_{dtype}', worst)
