@@ -74,34 +74,35 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     const T *pbase = ptab + hh * DHP;
 
     // tile loads: K/V rows j0 .. j0+63 (clamped), band rows B0 .. B0+127 (clamped), B0 = CEN - (i0b + 63) + j0
-    uint4 rk[KV_IT], rv[KV_IT], rp[P_IT];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rk[KV_IT], rv[KV_IT], rp[P_IT];
     auto load_tile = [&](int j0) {
         const int B0 = COCR_POS_CENTER - (i0b + 63) + j0;
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
             const size_t off = (size_t)min(j0 + row, Tn - 1) * DHP + ch * (16 / (int)sizeof(T));
-            rk[it] = *reinterpret_cast<const uint4 *>(kbase + off);
-            rv[it] = *reinterpret_cast<const uint4 *>(vbase + off);
+            rk[it] = *reinterpret_cast<const u32x4 *>(kbase + off);
+            rv[it] = *reinterpret_cast<const u32x4 *>(vbase + off);
         }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
             const int pr = min(max(B0 + row, 0), COCR_POS_ROWS - 1);
-            rp[it] = *reinterpret_cast<const uint4 *>(pbase + (size_t)pr * prow + ch * (16 / (int)sizeof(T)));
+            rp[it] = *reinterpret_cast<const u32x4 *>(pbase + (size_t)pr * prow + ch * (16 / (int)sizeof(T)));
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
-            *reinterpret_cast<uint4 *>(ks + row * RS + ch * 16) = rk[it];
-            *reinterpret_cast<uint4 *>(vs + row * RS + ch * 16) = rv[it];
+            *reinterpret_cast<u32x4 *>(ks + row * RS + ch * 16) = rk[it];
+            *reinterpret_cast<u32x4 *>(vs + row * RS + ch * 16) = rv[it];
         }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
-            *reinterpret_cast<uint4 *>(ps + row * RS + ch * 16) = rp[it];
+            *reinterpret_cast<u32x4 *>(ps + row * RS + ch * 16) = rp[it];
         }
     };
     load_tile(0);
@@ -133,11 +134,11 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
         __syncthreads();                       // every wave is done with the previous tile
         store_tile();
         __syncthreads();
-        if (j0 + 64 < Tn) load_tile(j0 + 64);  // in flight during the compute below
+        load_tile(j0 + 64 < Tn ? j0 + 64 : j0);   // in flight during the compute below (unconditional: the staging registers stay registers)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int js = j0 + 32 * s2;       // first key of this 32-key sub-tile
-            if (js >= Tn) break;               // uniform over the workgroup
+            if (js >= Tn) continue;            // uniform over the workgroup (no break: keeps the loop fully unrolled)
             // ---- content scores, transposed: rows = keys js + 16 tt + (4g + reg), column = query il
             f32x4 sc[2];
 #pragma unroll

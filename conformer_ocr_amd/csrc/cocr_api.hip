@@ -645,15 +645,38 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     }
     const int Tn = Tc, F = Fc, M = N * Tn, Tp = round_up(Tn, 32);
     float *x = m->x;
-    {   // flatten (b,t,(f,c)) is a view of the channel-last tensor; output linear writes the fp32 residual stream
-        ProfScope ps(m, s, FAM_FOUT);
-        EpiStoreF32 epi{x, D, F32(P.bout), D};
-        GEMM_TRY(launch_gemm<T>(s, zcur, F * C, WT(P.wout), F * C, M, D, F * C, epi));
-    }
-    if ((rc = tap<float>(m, s, "front.y", x, (size_t)M * D))) return rc;
-
     T *xn = (T *)m->xn, *hid = (T *)m->hid, *q = (T *)m->q, *k = (T *)m->k, *v = (T *)m->vt, *ctx = (T *)m->ctx, *glu = (T *)m->glu,
       *dwo = (T *)m->dwo;
+    const bool rowln = gemm_rowln_supported<T>(D);       // N == D products own whole rows: residual + LayerNorm in their epilogue
+    auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
+        ProfScope ps(m, s, FAM_LN);
+        launch_layernorm<T>(s, x, M, D, F32(g1), F32(b1), write_f32 ? x : nullptr, g2 >= 0 ? F32((size_t)g2) : nullptr,
+                            b2 >= 0 ? F32((size_t)b2) : nullptr, xn);
+        LAUNCH_CHECK();
+        return COCR_OK;
+    };
+    // x <- [x +] alpha (A W^T + bias); then the LayerNorm(s) that follow in the reference: xn <- LN1(x), or
+    // x <- LN1(x), xn <- LN2(x) (g2 >= 0: block-final LayerNorm chained with the next block's first)
+    auto gemm_to_stream = [&](int fam, const T *A, int K, size_t w, size_t bias, float alpha, bool resid, size_t g1, size_t b1, long g2,
+                              long b2) -> int {
+        if (rowln) {
+            ProfScope ps(m, s, fam);
+            EpiResidualLN<T, 1> e{x, D, F32(bias), alpha, D, resid ? 1 : 0, F32(g1), F32(b1), g2 >= 0 ? F32((size_t)g2) : nullptr,
+                                  b2 >= 0 ? F32((size_t)b2) : nullptr, xn};
+            GEMM_TRY(launch_gemm_rowln<T>(s, A, K, WT(w), K, M, D, K, e));
+            return COCR_OK;
+        }
+        {
+            ProfScope ps(m, s, fam);
+            if (resid) { EpiResidual e{x, D, F32(bias), alpha, D}; GEMM_TRY(launch_gemm<T>(s, A, K, WT(w), K, M, D, K, e)); }
+            else { EpiStoreF32 e{x, D, F32(bias), D}; GEMM_TRY(launch_gemm<T>(s, A, K, WT(w), K, M, D, K, e)); }
+        }
+        return ln(g1, b1, g2 >= 0, g2, b2);
+    };
+    // flatten (b,t,(f,c)) is a view of the channel-last tensor; the output linear writes the fp32 residual stream
+    if ((rc = gemm_to_stream(FAM_FOUT, zcur, F * C, P.wout, P.bout, 1.0f, false, P.layers[0].ffn[0].ln_g, P.layers[0].ffn[0].ln_b, -1, -1))) return rc;
+    if ((rc = tap<float>(m, s, "front.y", x, (size_t)M * D))) return rc;
+
     if (m->vtN != N || m->vtT != Tn) {   // pad dims of q, k, v must read as zero for this shape
         HIP_TRY(hipMemsetAsync(q, 0, m->qkv_bytes, s));
         HIP_TRY(hipMemsetAsync(k, 0, m->qkv_bytes, s));
@@ -663,26 +686,13 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
     const float scale = 1.0f / sqrtf((float)dh);
     char nm[64];
-    auto ffn = [&](const FfnW &w) -> int {
-        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.w1), D, M, ff, D, e)); }
-        { ProfScope ps(m, s, FAM_FFN_DOWN); EpiResidual e{x, D, F32(w.b2), ffr, D}; GEMM_TRY(launch_gemm<T>(s, hid, ff, WT(w.w2), ff, M, D, ff, e)); }
-        return COCR_OK;
-    };
-    auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
-        ProfScope ps(m, s, FAM_LN);
-        launch_layernorm<T>(s, x, M, D, F32(g1), F32(b1), write_f32 ? x : nullptr, g2 >= 0 ? F32((size_t)g2) : nullptr,
-                            b2 >= 0 ? F32((size_t)b2) : nullptr, xn);
-        LAUNCH_CHECK();
-        return COCR_OK;
-    };
     for (int l = 0; l < m->L; ++l) {
         const LayerW &w = P.layers[l];
-        if (l == 0 && (rc = ln(w.ffn[0].ln_g, w.ffn[0].ln_b, false, -1, -1))) return rc;
-        // FFN, half-step residual (feed_forward.py:45-52, encoder.py:68-75)
-        if ((rc = ffn(w.ffn[0]))) return rc;
+        // FFN, half-step residual (feed_forward.py:45-52, encoder.py:68-75); epilogue: LayerNorm of the attention module
+        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.ffn[0].b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.ffn[0].w1), D, M, ff, D, e)); }
+        if ((rc = gemm_to_stream(FAM_FFN_DOWN, hid, ff, w.ffn[0].w2, w.ffn[0].b2, ffr, true, w.a_ln_g, w.a_ln_b, -1, -1))) return rc;
         snprintf(nm, sizeof nm, "l%d.ffn1", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // MHSA (attention.py:143-151)
-        if ((rc = ln(w.a_ln_g, w.a_ln_b, false, -1, -1))) return rc;
         { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_ATTN);
@@ -697,37 +707,36 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             snprintf(nm, sizeof nm, "l%d.v", l); if ((rc = tap<T>(m, s, nm, v, m->qkv_bytes / sizeof(T)))) return rc;
             snprintf(nm, sizeof nm, "l%d.ctx", l); if ((rc = tap<T>(m, s, nm, ctx, (size_t)M * D))) return rc;
         }
-        { ProfScope ps(m, s, FAM_AOUT); EpiResidual e{x, D, F32(w.bo), 1.0f, D}; GEMM_TRY(launch_gemm<T>(s, ctx, D, WT(w.wo), D, M, D, D, e)); }
+        if ((rc = gemm_to_stream(FAM_AOUT, ctx, D, w.wo, w.bo, 1.0f, true, w.c_ln_g, w.c_ln_b, -1, -1))) return rc;
         snprintf(nm, sizeof nm, "l%d.mhsa", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // conv module (convolution.py:135-148)
-        if ((rc = ln(w.c_ln_g, w.c_ln_b, false, -1, -1))) return rc;
         { ProfScope ps(m, s, FAM_GLU); EpiGLU<T> e{glu, D, F32(w.bpw1), 2 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wpw1), D, M, 2 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_DW);
-            constexpr int TT = 16;
-            const size_t lds = (size_t)(TT + m->ksz - 1) * 128 * 2 * sizeof(T);
-            hipLaunchKernelGGL((dwconv_bn_silu_kernel<T, TT>), dim3(ceil_div(Tn, TT), N, ceil_div(D, 256)), dim3(128), lds, s, glu, Tn, D, m->ksz,
-                               F32(w.dww), F32(w.dwb), dwo);
+            launch_dwconv<T>(s, glu, N, Tn, D, m->ksz, F32(w.dww), F32(w.dwb), dwo);
             LAUNCH_CHECK();
         }
         if (m->debug) {
             snprintf(nm, sizeof nm, "l%d.glu", l); if ((rc = tap<T>(m, s, nm, glu, (size_t)M * D))) return rc;
             snprintf(nm, sizeof nm, "l%d.dw", l); if ((rc = tap<T>(m, s, nm, dwo, (size_t)M * D))) return rc;
         }
-        { ProfScope ps(m, s, FAM_PW2); EpiResidual e{x, D, F32(w.bpw2), 1.0f, D}; GEMM_TRY(launch_gemm<T>(s, dwo, D, WT(w.wpw2), D, M, D, D, e)); }
+        if ((rc = gemm_to_stream(FAM_PW2, dwo, D, w.wpw2, w.bpw2, 1.0f, true, w.ffn[1].ln_g, w.ffn[1].ln_b, -1, -1))) return rc;
         snprintf(nm, sizeof nm, "l%d.conv", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
-        // second FFN
-        if ((rc = ln(w.ffn[1].ln_g, w.ffn[1].ln_b, false, -1, -1))) return rc;
-        if ((rc = ffn(w.ffn[1]))) return rc;
-        snprintf(nm, sizeof nm, "l%d.ffn2", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
-        // block-final LayerNorm (encoder.py:99), chained with the next block's first LayerNorm
-        if (l + 1 < m->L) {
+        // second FFN; its epilogue applies the block-final LayerNorm (encoder.py:99) chained with the next block's first
+        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.ffn[1].b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.ffn[1].w1), D, M, ff, D, e)); }
+        if (m->debug) {
+            // taps want the stream before and after the closing LayerNorm separately: unfused in debug mode
+            { ProfScope ps(m, s, FAM_FFN_DOWN); EpiResidual e{x, D, F32(w.ffn[1].b2), ffr, D}; GEMM_TRY(launch_gemm<T>(s, hid, ff, WT(w.ffn[1].w2), ff, M, D, ff, e)); }
+            snprintf(nm, sizeof nm, "l%d.ffn2", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
+            if (l + 1 < m->L) { if ((rc = ln(w.f_ln_g, w.f_ln_b, true, (long)P.layers[l + 1].ffn[0].ln_g, (long)P.layers[l + 1].ffn[0].ln_b))) return rc; }
+            else if ((rc = ln(w.f_ln_g, w.f_ln_b, true, -1, -1))) return rc;
+            snprintf(nm, sizeof nm, "l%d.out", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
+        } else if (l + 1 < m->L) {
             const LayerW &nx = P.layers[l + 1];
-            if ((rc = ln(w.f_ln_g, w.f_ln_b, true, (long)nx.ffn[0].ln_g, (long)nx.ffn[0].ln_b))) return rc;
+            if ((rc = gemm_to_stream(FAM_FFN_DOWN, hid, ff, w.ffn[1].w2, w.ffn[1].b2, ffr, true, w.f_ln_g, w.f_ln_b, (long)nx.ffn[0].ln_g, (long)nx.ffn[0].ln_b))) return rc;
         } else {
-            if ((rc = ln(w.f_ln_g, w.f_ln_b, m->debug, -1, -1))) return rc;
+            if ((rc = gemm_to_stream(FAM_FFN_DOWN, hid, ff, w.ffn[1].w2, w.ffn[1].b2, ffr, true, w.f_ln_g, w.f_ln_b, -1, -1))) return rc;
         }
-        snprintf(nm, sizeof nm, "l%d.out", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
     }
     {   // decoder nn.Linear (pred.py:90,121): logits fp32
         ProfScope ps(m, s, FAM_DEC);
@@ -787,8 +796,10 @@ extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T,
         m->ctc_cap = (size_t)N * T;
     }
     ProfScope ps(m, s, FAM_GREEDY);
-    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(N), dim3(256), 0, s, logits, T, ncls, m->d_lens, labels, starts, ends, conf, counts,
-                       max_per_line, m->ctc_lab, m->ctc_val);
+    hipLaunchKernelGGL(ctc_argmax_kernel, dim3(ceil_div(N * T, 4)), dim3(256), 0, s, logits, T, ncls, N * T, m->d_lens, m->ctc_lab, m->ctc_val);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(64), 0, s, T, m->d_lens, m->ctc_lab, m->ctc_val, labels, starts, ends, conf, counts,
+                       max_per_line);
     LAUNCH_CHECK();
     return COCR_OK;
 }
@@ -811,6 +822,7 @@ __global__ void fill_kernel(unsigned short *p, size_t n, unsigned seed, int as_f
 struct EpiNull {   // ablation: keeps the accumulators alive, stores (almost) nothing
     typedef float stage_t;
     static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = false;
     float *sink;
     __device__ __forceinline__ void transform(int n, const float *v, float *r) const { for (int i = 0; i < 4; ++i) r[i] = v[i]; }
     __device__ __forceinline__ void store(int m, int c, const float *src, int cnt) const { if (src[0] == 123.456f) sink[0] = 1.0f; }

@@ -149,3 +149,65 @@ __global__ __launch_bounds__(128) void dwconv_bn_silu_kernel(const T *__restrict
         }
     }
 }
+
+// Compile-time-k variant: the TT + K - 1 input frames of the thread's channel pair are loaded up front (all
+// loads in flight together), taps and accumulators live in registers, the (frame, tap) loops are fully
+// unrolled -- no LDS.  Same arithmetic order per output as the generic kernel (taps ascending).
+template <typename T, int K, int TT>
+__global__ __launch_bounds__(128) void dwconv_bn_silu_k_kernel(const T *__restrict__ g, int Tn, int D,
+                                                               const float *__restrict__ w, const float *__restrict__ bias,
+                                                               T *__restrict__ out) {
+    typedef typename Pair<T>::type P2;
+    constexpr int PAD = (K - 1) / 2, ROWS = TT + K - 1;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT, c = blockIdx.z * 256 + 2 * threadIdx.x;
+    if (c >= D) return;
+    const T *gb = g + (size_t)b * Tn * D + c;
+    P2 xin[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int t = t0 + r - PAD;
+        // clamped address + select (a branch around each load would serialise the ROWS loads)
+        P2 v = *reinterpret_cast<const P2 *>(gb + (size_t)min(max(t, 0), Tn - 1) * D);
+        if (t < 0 || t >= Tn) { v[0] = (T)0.0f; v[1] = (T)0.0f; }
+        xin[r] = v;
+    }
+    float w0[K], w1[K];
+#pragma unroll
+    for (int tau = 0; tau < K; ++tau) {
+        const f32x2 ww = *reinterpret_cast<const f32x2 *>(w + (size_t)tau * D + c);
+        w0[tau] = ww[0]; w1[tau] = ww[1];
+    }
+    const f32x2 bb = *reinterpret_cast<const f32x2 *>(bias + c);
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        float a0 = bb[0], a1 = bb[1];
+#pragma unroll
+        for (int tau = 0; tau < K; ++tau) {
+            a0 += w0[tau] * to_f32(xin[i + tau][0]);
+            a1 += w1[tau] * to_f32(xin[i + tau][1]);
+        }
+        const int t = t0 + i;
+        if (t < Tn) {
+            P2 o; o[0] = from_f32<T>(silu_f(a0)); o[1] = from_f32<T>(silu_f(a1));
+            *reinterpret_cast<P2 *>(out + ((size_t)b * Tn + t) * D + c) = o;
+        }
+    }
+}
+
+template <typename T>
+static inline void launch_dwconv(hipStream_t s, const T *g, int N, int Tn, int D, int k, const float *w, const float *bias, T *out) {
+    constexpr int TT = 16;
+    dim3 grid(ceil_div(Tn, TT), N, ceil_div(D, 256));
+#define DWK(KK) hipLaunchKernelGGL((dwconv_bn_silu_k_kernel<T, KK, TT>), grid, dim3(128), 0, s, g, Tn, D, w, bias, out)
+    switch (k) {
+        case 7: DWK(7); break;
+        case 9: DWK(9); break;
+        case 15: DWK(15); break;
+        case 31: DWK(31); break;
+        default: {
+            const size_t lds = (size_t)(TT + k - 1) * 128 * 2 * sizeof(T);
+            hipLaunchKernelGGL((dwconv_bn_silu_kernel<T, TT>), grid, dim3(128), lds, s, g, Tn, D, k, w, bias, out);
+        }
+    }
+#undef DWK
+}

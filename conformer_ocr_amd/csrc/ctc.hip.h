@@ -7,44 +7,46 @@
 #include "common.hip.h"
 
 // ---- greedy: argmax per frame (first index on ties, like numpy), merge runs, drop blank ---------
-// One workgroup per line.  Phase 1: each wave takes frames t = wave, wave+4, ...: lanes stride the
-// classes (coalesced), keep (value, index) with strict > so the lowest index wins inside a lane, then a
-// butterfly that prefers the larger value and, on equality, the lower index.  Phase 2: one wave
-// scans the frame labels in chunks of 64: a frame opens a run if its label differs from its
-// predecessor's; ballot + popcount give each non-blank run its output slot; the run's end and
-// confidence are found by walking forward.  HBM-bound: algorithmic bytes = N*T*ncls*4 read.
-#define COCR_CTC_MAX_T 8192
-
-__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float *__restrict__ logits, int T, int ncls,
+// Per frame: lanes stride the classes (coalesced), keep (value, index) with strict > so the lowest index wins
+// inside a lane, then a butterfly that prefers the larger value and, on equality, the lower index.
+// HBM-bound: algorithmic bytes = N*T*ncls*4 read.
+// Two launches: (1) one wave per frame over the whole batch (N*T waves: fills the chip) writes the frame's
+// argmax label and max logit; (2) one wave per line scans the frame labels in chunks of 64: a frame opens a run
+// if its label differs from its predecessor's; ballot + popcount give each non-blank run its output slot; the
+// run's end and confidence are found by walking forward.
+__global__ __launch_bounds__(256) void ctc_argmax_kernel(const float *__restrict__ logits, int T, int ncls, int frames,
                                                          const int32_t *__restrict__ lens,
-                                                         int32_t *__restrict__ labels, int32_t *__restrict__ starts,
-                                                         int32_t *__restrict__ ends, float *__restrict__ conf,
-                                                         int32_t *__restrict__ counts, int max_per_line,
-                                                         int32_t *__restrict__ scratch_lab, float *__restrict__ scratch_val) {
-    const int n = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int len = min(max(lens[n], 0), T);
-    const float *lg = logits + (size_t)n * T * ncls;
-    int32_t *flab = scratch_lab + (size_t)n * T;      // per-frame argmax label
-    float *fval = scratch_val + (size_t)n * T;        // per-frame max logit
-    for (int t = wave; t < len; t += 4) {
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int c = lane; c < ncls; c += 64) {
-            const float v = lg[(size_t)t * ncls + c];
-            if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        if (lane == 0) { flab[t] = bi; fval[t] = best; }
+                                                         int32_t *__restrict__ flab, float *__restrict__ fval) {
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);          // frame index n * T + t
+    if (f >= frames) return;
+    const int n = f / T, t = f - n * T;
+    if (t >= lens[n]) return;                                  // frames beyond the line's length are never read
+    const float *lg = logits + (size_t)f * ncls;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < ncls; c += 64) {
+        const float v = lg[c];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
     }
-    __threadfence_block();
-    __syncthreads();
-    if (wave != 0) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { flab[f] = bi; fval[f] = best; }
+}
+
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(int T, const int32_t *__restrict__ lens, const int32_t *__restrict__ flab_all,
+                                                          const float *__restrict__ fval_all,
+                                                          int32_t *__restrict__ labels, int32_t *__restrict__ starts,
+                                                          int32_t *__restrict__ ends, float *__restrict__ conf,
+                                                          int32_t *__restrict__ counts, int max_per_line) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int len = min(max(lens[n], 0), T);
+    const int32_t *flab = flab_all + (size_t)n * T;
+    const float *fval = fval_all + (size_t)n * T;
     int emitted = 0;
     for (int base = 0; base < len; base += 64) {
         const int t = base + lane;

@@ -51,6 +51,7 @@ template <typename U> __device__ __forceinline__ void copy16(U *dst, const U *sr
 template <typename T, int ACT> struct EpiBiasAct {
     typedef T stage_t;
     static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = false;
     T *out; int ldo; const float *bias; int N;
     __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
 #pragma unroll
@@ -72,6 +73,7 @@ template <typename T, int ACT> struct EpiBiasAct {
 struct EpiStoreF32 {
     typedef float stage_t;
     static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = false;
     float *out; int ldo; const float *bias; int N;
     __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
 #pragma unroll
@@ -88,6 +90,7 @@ struct EpiStoreF32 {
 struct EpiResidual {
     typedef float stage_t;
     static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = false;
     float *x; int ldx; const float *bias; float alpha; int N;
     __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
 #pragma unroll
@@ -112,6 +115,7 @@ struct EpiResidual {
 template <typename T> struct EpiGLU {
     typedef T stage_t;
     static constexpr bool GLU = true;
+    static constexpr bool ROWWISE = false;
     T *out; int ldo; const float *bias; int N;
     __device__ __forceinline__ void transform(int n, const float *v, const float *gte, float *r) const {
 #pragma unroll
@@ -129,6 +133,7 @@ template <typename T> struct EpiGLU {
 template <typename T> struct EpiQKV {
     typedef T stage_t;
     static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = false;
     T *q, *k, *v; const float *bias; int D, dh, dhp, heads, T_, Tp, N;
     __device__ __forceinline__ void transform(int n, const float *a, float *r) const {
 #pragma unroll
@@ -151,6 +156,7 @@ template <typename T> struct EpiQKV {
 template <typename T> struct EpiPosTable {
     typedef T stage_t;
     static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = false;
     T *out; int dh, dhp, heads;
     __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
 #pragma unroll
@@ -161,6 +167,106 @@ template <typename T> struct EpiPosTable {
             const int hh = (c + i) / dh, d = (c + i) - hh * dh;
             out[((size_t)m * heads + hh) * dhp + d] = src[i];
         }
+    }
+};
+
+// Row-complete epilogue for the N == encoder_dim products (frontend output linear, FFN down, attention out,
+// conv-module pointwise 2): requires BN >= N so that a workgroup owns whole rows.  After the accumulator tile
+// (alpha * (acc + bias)) is staged in LDS, each wave takes 4 rows at a time and, with the row in registers,
+//   x_new = x + staged                      (ResidualConnectionModule, modules.py:32; no `x +` for the frontend)
+//   single:  x <- x_new ;            xn <- LN1(x_new)                 (the next module's LayerNorm)
+//   chained: x <- LN1(x_new) ;       xn <- LN2(LN1(x_new))            (block-final LayerNorm encoder.py:99 + next FFN's)
+// so no standalone LayerNorm launch and no re-read of the stream is left in a block.
+template <typename T, int NV> struct EpiResidualLN {
+    typedef float stage_t;
+    static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = true;
+    float *x; int D; const float *bias; float alpha; int N; int has_resid;
+    const float *g1, *b1, *g2, *b2;
+    T *xn;
+    __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = alpha * (v[i] + (n + i < N ? bias[n + i] : 0.f));
+    }
+    // rows m0 .. m0+3 (row r valid if m0 + r < M); staged row r at `staged + r * rs_floats`
+    __device__ __forceinline__ void rows4(int m0, int M, const float *staged, int rs_floats, int lane) const {
+        const int nchunk = D >> 2;
+        const float inv_d = 1.0f / (float)D;
+        f32x4 xv[4][NV];
+        float s[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[r] = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = lane + 64 * v;
+                f32x4 t = (f32x4){0, 0, 0, 0};
+                if (c < nchunk) {
+                    t = *reinterpret_cast<const f32x4 *>(staged + r * rs_floats + 4 * c);
+                    if (has_resid && m0 + r < M) t += *reinterpret_cast<const f32x4 *>(x + (size_t)(m0 + r) * D + 4 * c);
+                }
+                xv[r][v] = t;
+                s[r] += t[0] + t[1] + t[2] + t[3];
+            }
+        }
+        auto write_x = [&]() {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int c = lane + 64 * v;
+                    if (m0 + r < M && c < nchunk) *reinterpret_cast<f32x4 *>(x + (size_t)(m0 + r) * D + 4 * c) = xv[r][v];
+                }
+        };
+        auto normalise = [&](const float *gam, const float *bet) {
+            float mean[4], q[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mean[r] = wave_sum(s[r]) * inv_d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                q[r] = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const bool ok = lane + 64 * v < nchunk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = ok ? xv[r][v][e] - mean[r] : 0.f; q[r] += d * d; }
+                }
+            }
+            float rstd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(q[r]) * inv_d + 1e-5f);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = lane + 64 * v;
+                const bool ok = c < nchunk;
+                const f32x4 ga = ok ? *reinterpret_cast<const f32x4 *>(gam + 4 * c) : (f32x4){0, 0, 0, 0};
+                const f32x4 be = ok ? *reinterpret_cast<const f32x4 *>(bet + 4 * c) : (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[r][v][e] = (xv[r][v][e] - mean[r]) * rstd[r] * ga[e] + be[e];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s[r] += xv[r][v][0] + xv[r][v][1] + xv[r][v][2] + xv[r][v][3];
+            }
+        };
+        if (!g2) write_x();
+        normalise(g1, b1);
+        if (g2) { write_x(); normalise(g2, b2); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = lane + 64 * v;
+                if (m0 + r < M && c < nchunk) {
+                    T *p = xn + (size_t)(m0 + r) * D + 4 * c;
+                    if constexpr (sizeof(T) == 2) { bf16x4 o = {(T)xv[r][v][0], (T)xv[r][v][1], (T)xv[r][v][2], (T)xv[r][v][3]}; *reinterpret_cast<bf16x4 *>(p) = o; }
+                    else { *reinterpret_cast<f32x4 *>(p) = xv[r][v]; }
+                }
+            }
     }
 };
 
@@ -212,11 +318,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], unsigned cha
         }
     }
     __syncthreads();
-    const int c0 = Epi::GLU ? n0 / 2 : n0, cend = Epi::GLU ? N / 2 : N;     // staged-column range of this tile in the output
-    for (int id = threadIdx.x; id < BM * CPR; id += 256) {
-        const int row = id / CPR, ch = id - row * CPR;
-        const int m = m0 + row, c = c0 + ch * CH;
-        if (m < M && c < cend) epi.store(m, c, reinterpret_cast<const S *>(smem + row * RS) + ch * CH, min(CH, cend - c));
+    if constexpr (Epi::ROWWISE) {      // BN >= N: the tile holds complete rows (n0 == 0)
+        static_assert(BM % 16 == 0, "4 waves x 4 rows");
+        for (int rr = wave * 4; rr < BM; rr += 16)
+            epi.rows4(m0 + rr, M, reinterpret_cast<const float *>(smem + rr * RS), RS / 4, lane);
+    } else {
+        const int c0 = Epi::GLU ? n0 / 2 : n0, cend = Epi::GLU ? N / 2 : N;     // staged-column range of this tile in the output
+        for (int id = threadIdx.x; id < BM * CPR; id += 256) {
+            const int row = id / CPR, ch = id - row * CPR;
+            const int m = m0 + row, c = c0 + ch * CH;
+            if (m < M && c < cend) epi.store(m, c, reinterpret_cast<const S *>(smem + row * RS) + ch * CH, min(CH, cend - c));
+        }
     }
 }
 
@@ -330,31 +442,32 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs<T> p, Epi epi
     const int ltile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (ltile / gx) * BM, n0 = (ltile % gx) * BN;
 
-    uint4 ra[A_IT], rw[W_IT];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[A_IT], rw[W_IT];
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
             const int m = m0 + row, k = k0 + ch * EPC;
-            ra[it] = (m < M && k < K) ? *reinterpret_cast<const uint4 *>(p.A + (size_t)m * p.lda + k) : make_uint4(0, 0, 0, 0);
+            ra[it] = (m < M && k < K) ? *reinterpret_cast<const u32x4 *>(p.A + (size_t)m * p.lda + k) : (u32x4){0, 0, 0, 0};
         }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
             const int n = n0 + row, k = k0 + ch * EPC;
-            rw[it] = (n < N && k < K) ? *reinterpret_cast<const uint4 *>(p.W + (size_t)n * p.ldw + k) : make_uint4(0, 0, 0, 0);
+            rw[it] = (n < N && k < K) ? *reinterpret_cast<const u32x4 *>(p.W + (size_t)n * p.ldw + k) : (u32x4){0, 0, 0, 0};
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4 *>(a_area + (buf * BM + row) * STRIDE + ch * 16) = ra[it];
+            *reinterpret_cast<u32x4 *>(a_area + (buf * BM + row) * STRIDE + ch * 16) = ra[it];
         }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int id = it * 256 + tid, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4 *>(w_area + (buf * BN + row) * STRIDE + ch * 16) = rw[it];
+            *reinterpret_cast<u32x4 *>(w_area + (buf * BN + row) * STRIDE + ch * 16) = rw[it];
         }
     };
     f32x4 acc[MI][NI];
@@ -434,4 +547,14 @@ static inline hipError_t launch_gemm(hipStream_t s, const T *A, int lda, const T
     }
     if (t128 >= 1024) return launch_stream_cfg<T, 128, 128, Epi>(s, a, epi);
     return launch_stream_cfg<T, 64, 64, Epi>(s, a, epi);
+}
+
+// Row-complete product (N == encoder_dim <= 256) with the fused residual + LayerNorm epilogue: 32 x 256 tiles.
+template <typename T> static inline bool gemm_rowln_supported(int N) { return N <= 256 && (N & 3) == 0; }
+template <typename T, typename Epi>
+static inline hipError_t launch_gemm_rowln(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, const Epi &epi) {
+    GemmArgs<T> a{A, lda, W, ldw, M, N, K};
+    constexpr int BK = 128 / (int)sizeof(T);
+    if (K % BK == 0) return launch_ring_cfg<T, 32, 256, 2, Epi>(s, a, epi);
+    return launch_stream_cfg<T, 32, 256, Epi>(s, a, epi);
 }
