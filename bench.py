@@ -50,6 +50,7 @@ def kernel_table(hp, n, w, dtype):
         'layernorm': ('hbm', M * D * (4 + es)),
         'gemm_ffn_up': ('mfma', 2.0 * M * D * ff),
         'gemm_ffn_down': ('mfma', 2.0 * M * D * ff),
+        'ffn_fused': ('mfma', 4.0 * M * D * ff),
         'gemm_qkv': ('mfma', 2.0 * M * D * 3 * D),
         'attention': ('mfma', 2.0 * n * 3 * T * T * D),
         'gemm_attn_out': ('mfma', 2.0 * M * D * D),

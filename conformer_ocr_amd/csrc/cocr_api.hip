@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -21,6 +22,7 @@
 #include "conv.hip.h"
 #include "ctc.hip.h"
 #include "gemm.hip.h"
+#include "ffn.hip.h"
 #include "norm.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
@@ -96,6 +98,7 @@ struct cocr_model {
     int lens_cap = 0;
     // debug / profile
     bool debug = false;
+    bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
     bool profile = false;
     std::vector<ProfRec> prof;
@@ -103,9 +106,9 @@ struct cocr_model {
 };
 
 static const char *FAMILIES[] = {"frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
-                                 "gemm_ffn_up", "gemm_ffn_down", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
+                                 "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
                                  "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam"};
-enum { FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
+enum { FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
        FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_COUNT };
 
 static int out_len1(int l) { return l >= 1 ? (l - 1) / 2 + 1 : 0; }
@@ -142,6 +145,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     m->heads = hp->num_attention_heads; m->dh = dh; m->dhp = round_up(dh, 32);
     m->ff = hp->feed_forward_expansion_factor * hp->encoder_dim; m->ksz = hp->conv_kernel_size;
     m->ncls = hp->num_classes; m->H = hp->height; m->snum = snum;
+    { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
     int f = hp->height;
     for (int i = 0; i < snum; ++i) { f = out_len1(f); m->feats.push_back(f); }
     // expected state-dict entries, reference key names
@@ -647,6 +651,8 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     float *x = m->x;
     T *xn = (T *)m->xn, *hid = (T *)m->hid, *q = (T *)m->q, *k = (T *)m->k, *v = (T *)m->vt, *ctx = (T *)m->ctx, *glu = (T *)m->glu,
       *dwo = (T *)m->dwo;
+    const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
+    const float scale = 1.0f / sqrtf((float)dh);
     const bool rowln = gemm_rowln_supported<T>(D);       // N == D products own whole rows: residual + LayerNorm in their epilogue
     auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
         ProfScope ps(m, s, FAM_LN);
@@ -673,6 +679,20 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         }
         return ln(g1, b1, g2 >= 0, g2, b2);
     };
+    // feed-forward module + the LayerNorm(s) that follow it.  bf16, D == 256: one fused kernel (hidden stays on chip)
+    auto ffn = [&](const FfnW &fw, size_t g1, size_t b1, long g2, long b2) -> int {
+        if constexpr (sizeof(T) == 2) {
+            if (rowln && ffn_fused_supported<int>(D, ff) && !m->no_fused_ffn) {
+                ProfScope ps(m, s, FAM_FFN_FUSED);
+                EpiResidualLN<T, 1> e{x, D, F32(fw.b2), ffr, D, 1, F32(g1), F32(b1), g2 >= 0 ? F32((size_t)g2) : nullptr,
+                                      b2 >= 0 ? F32((size_t)b2) : nullptr, xn};
+                GEMM_TRY(launch_ffn_fused(s, (const bf16_t *)xn, (const bf16_t *)WT(fw.w1), F32(fw.b1), (const bf16_t *)WT(fw.w2), M, D, ff, e));
+                return COCR_OK;
+            }
+        }
+        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(fw.b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(fw.w1), D, M, ff, D, e)); }
+        return gemm_to_stream(FAM_FFN_DOWN, hid, ff, fw.w2, fw.b2, ffr, true, g1, b1, g2, b2);
+    };
     // flatten (b,t,(f,c)) is a view of the channel-last tensor; the output linear writes the fp32 residual stream
     if ((rc = gemm_to_stream(FAM_FOUT, zcur, F * C, P.wout, P.bout, 1.0f, false, P.layers[0].ffn[0].ln_g, P.layers[0].ffn[0].ln_b, -1, -1))) return rc;
     if ((rc = tap<float>(m, s, "front.y", x, (size_t)M * D))) return rc;
@@ -683,14 +703,11 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         HIP_TRY(hipMemsetAsync(v, 0, m->qkv_bytes, s));
         m->vtN = N; m->vtT = Tn;
     }
-    const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
-    const float scale = 1.0f / sqrtf((float)dh);
     char nm[64];
     for (int l = 0; l < m->L; ++l) {
         const LayerW &w = P.layers[l];
         // FFN, half-step residual (feed_forward.py:45-52, encoder.py:68-75); epilogue: LayerNorm of the attention module
-        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.ffn[0].b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.ffn[0].w1), D, M, ff, D, e)); }
-        if ((rc = gemm_to_stream(FAM_FFN_DOWN, hid, ff, w.ffn[0].w2, w.ffn[0].b2, ffr, true, w.a_ln_g, w.a_ln_b, -1, -1))) return rc;
+        if ((rc = ffn(w.ffn[0], w.a_ln_g, w.a_ln_b, -1, -1))) return rc;
         snprintf(nm, sizeof nm, "l%d.ffn1", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // MHSA (attention.py:143-151)
         { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
@@ -723,9 +740,9 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         if ((rc = gemm_to_stream(FAM_PW2, dwo, D, w.wpw2, w.bpw2, 1.0f, true, w.ffn[1].ln_g, w.ffn[1].ln_b, -1, -1))) return rc;
         snprintf(nm, sizeof nm, "l%d.conv", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         // second FFN; its epilogue applies the block-final LayerNorm (encoder.py:99) chained with the next block's first
-        { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.ffn[1].b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.ffn[1].w1), D, M, ff, D, e)); }
         if (m->debug) {
             // taps want the stream before and after the closing LayerNorm separately: unfused in debug mode
+            { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(w.ffn[1].b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.ffn[1].w1), D, M, ff, D, e)); }
             { ProfScope ps(m, s, FAM_FFN_DOWN); EpiResidual e{x, D, F32(w.ffn[1].b2), ffr, D}; GEMM_TRY(launch_gemm<T>(s, hid, ff, WT(w.ffn[1].w2), ff, M, D, ff, e)); }
             snprintf(nm, sizeof nm, "l%d.ffn2", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
             if (l + 1 < m->L) { if ((rc = ln(w.f_ln_g, w.f_ln_b, true, (long)P.layers[l + 1].ffn[0].ln_g, (long)P.layers[l + 1].ffn[0].ln_b))) return rc; }
@@ -733,9 +750,9 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             snprintf(nm, sizeof nm, "l%d.out", l); if ((rc = tap<float>(m, s, nm, x, (size_t)M * D))) return rc;
         } else if (l + 1 < m->L) {
             const LayerW &nx = P.layers[l + 1];
-            if ((rc = gemm_to_stream(FAM_FFN_DOWN, hid, ff, w.ffn[1].w2, w.ffn[1].b2, ffr, true, w.f_ln_g, w.f_ln_b, (long)nx.ffn[0].ln_g, (long)nx.ffn[0].ln_b))) return rc;
+            if ((rc = ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, (long)nx.ffn[0].ln_g, (long)nx.ffn[0].ln_b))) return rc;
         } else {
-            if ((rc = gemm_to_stream(FAM_FFN_DOWN, hid, ff, w.ffn[1].w2, w.ffn[1].b2, ffr, true, w.f_ln_g, w.f_ln_b, -1, -1))) return rc;
+            if ((rc = ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, -1, -1))) return rc;
         }
     }
     {   // decoder nn.Linear (pred.py:90,121): logits fp32
@@ -861,6 +878,12 @@ extern "C" int cocr_dev_bench_gemm(int variant, int M, int N, int K, int iters, 
             case 9: return resid ? launch_stream_cfg<T, 64, 64>(0, a, er) : launch_stream_cfg<T, 64, 64>(0, a, eh);
             case 30: return launch_ring_cfg<T, 128, 128, 2>(0, a, en);
             case 31: return launch_ring_cfg<T, 64, 64, 3>(0, a, en);
+            case 40: case 41: case 42: {   // fused FFN on (M, D=256, FF=N): A = xn [M][256], W = W1 [N][256], O reused as W2 [256][N]
+                EpiResidualLN<T, 1> e{X, 256, bias, 0.5f, 256, 1, gam, gam, nullptr, nullptr, (T *)A};
+                if (variant == 40) return launch_ffn_fused<EpiResidualLN<T, 1>, 0>(0, (const T *)A, (const T *)W, bias, (const T *)O, M, 256, N, e);
+                if (variant == 41) return launch_ffn_fused<EpiResidualLN<T, 1>, 1>(0, (const T *)A, (const T *)W, bias, (const T *)O, M, 256, N, e);
+                return launch_ffn_fused<EpiResidualLN<T, 1>, 2>(0, (const T *)A, (const T *)W, bias, (const T *)O, M, 256, N, e);
+            }
             case 20: launch_layernorm<T>(0, X, M, K, gam, gam, nullptr, nullptr, nullptr, (T *)A); return hipGetLastError();
             case 21: launch_layernorm<T>(0, X, M, K, gam, gam, X, gam, gam, (T *)A); return hipGetLastError();
             default: return hipErrorInvalidValue;

@@ -200,11 +200,12 @@ template <typename T, int NV> struct EpiResidualLN {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int c = lane + 64 * v;
-                f32x4 t = (f32x4){0, 0, 0, 0};
-                if (c < nchunk) {
-                    t = *reinterpret_cast<const f32x4 *>(staged + r * rs_floats + 4 * c);
-                    if (has_resid && m0 + r < M) t += *reinterpret_cast<const f32x4 *>(x + (size_t)(m0 + r) * D + 4 * c);
-                }
+                // unconditional, clamped loads + selects: a branch around each load would serialise the 4 rows' round trips
+                const int cc = min(c, nchunk - 1);
+                f32x4 t = *reinterpret_cast<const f32x4 *>(staged + r * rs_floats + 4 * cc);
+                const f32x4 xr = *reinterpret_cast<const f32x4 *>(x + (size_t)min(m0 + r, M - 1) * D + 4 * cc);
+                if (has_resid) t += xr;
+                if (c >= nchunk) t = (f32x4){0, 0, 0, 0};
                 xv[r][v] = t;
                 s[r] += t[0] + t[1] + t[2] + t[3];
             }

@@ -14,6 +14,8 @@ plain = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 30, 31, 20, 21]
 if len(sys.argv) > 1:
     plain = [int(x) for x in sys.argv[1].split(',')]
 ln = [10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
+if len(sys.argv) > 2:
+    shapes = {k: v for k, v in shapes.items() if k in sys.argv[2].split(',')}
 for name, (M, N, K) in shapes.items():
     vs = plain + (ln if (K == 256 and len(sys.argv) <= 1 and False) else [])
     row = []
