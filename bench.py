@@ -102,7 +102,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=3)
-    ap.add_argument('--streams', type=int, default=1, help='independent batches in flight (one packed model + HIP stream each)')
+    ap.add_argument('--streams', type=int, default=3, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))

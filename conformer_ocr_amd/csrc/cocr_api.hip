@@ -801,6 +801,7 @@ extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T,
                                int32_t *starts, int32_t *ends, float *conf, int32_t *counts, int max_per_line, void *stream) {
     if (!m || !logits || !out_lens || !labels || !starts || !ends || !conf || !counts) return fail(COCR_EINVAL, "null argument");
     if (N < 1 || T < 1 || ncls < 1 || max_per_line < 1) return fail(COCR_EINVAL, "empty problem");
+    if (T > 8000) return fail(COCR_EUNSUPPORTED, "more than 8000 frames per line");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     int rc = upload_lens(m, out_lens, N, s);
@@ -815,7 +816,7 @@ extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T,
     ProfScope ps(m, s, FAM_GREEDY);
     hipLaunchKernelGGL(ctc_argmax_kernel, dim3(ceil_div(N * T, 4)), dim3(256), 0, s, logits, T, ncls, N * T, m->d_lens, m->ctc_lab, m->ctc_val);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(64), 0, s, T, m->d_lens, m->ctc_lab, m->ctc_val, labels, starts, ends, conf, counts,
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(64), (size_t)T * 8, s, T, m->d_lens, m->ctc_lab, m->ctc_val, labels, starts, ends, conf, counts,
                        max_per_line);
     LAUNCH_CHECK();
     return COCR_OK;

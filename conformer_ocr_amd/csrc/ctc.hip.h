@@ -43,10 +43,16 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(int T, const int32_t *
                                                           int32_t *__restrict__ labels, int32_t *__restrict__ starts,
                                                           int32_t *__restrict__ ends, float *__restrict__ conf,
                                                           int32_t *__restrict__ counts, int max_per_line) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ctc_smem[];   // the line's frame labels and maxima: the run walk
+    int32_t *flab = reinterpret_cast<int32_t *>(ctc_smem);                      // below is a chain of dependent reads
+    float *fval = reinterpret_cast<float *>(ctc_smem) + T;
     const int n = blockIdx.x, lane = threadIdx.x;
     const int len = min(max(lens[n], 0), T);
-    const int32_t *flab = flab_all + (size_t)n * T;
-    const float *fval = fval_all + (size_t)n * T;
+    for (int t = lane; t < len; t += 64) {
+        flab[t] = flab_all[(size_t)n * T + t];
+        fval[t] = fval_all[(size_t)n * T + t];
+    }
+    __syncthreads();
     int emitted = 0;
     for (int base = 0; base < len; base += 64) {
         const int t = base + lane;
