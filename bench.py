@@ -102,6 +102,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a captured hipGraph')
     ap.add_argument('--streams', type=int, default=3, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
 
@@ -143,6 +144,10 @@ def main():
     for e in engines:
         e.reserve(args.batch, args.width)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    T_out = eng.out_len(args.width)
+    outs = [torch.empty((args.batch, T_out, hp.num_classes), dtype=torch.float32, device=dev) for _ in range(S)]
+    for e in engines:
+        e.set_graph(not args.no_graph)
 
     def run_steps(n):
         """n steps; step i is enqueued on stream i % S (forward + greedy decode + D2H of the label records) and its
@@ -151,7 +156,7 @@ def main():
         for i in range(n):
             e = engines[i % S]
             with torch.cuda.stream(streams[i % S]):
-                logits, out_lens = e.forward(x, lens32)
+                logits, out_lens = e.forward(x, lens32, out=outs[i % S])
                 pending.append((e, e.ctc_greedy_async(logits, out_lens)))
             if len(pending) >= S:
                 pe, h = pending.pop(0)
@@ -185,6 +190,7 @@ def main():
     # ---- roofline of the dominant kernel: HIP events around every launch, on the forward's stream
     roof, kernels = None, {}
     if rank == 0 and args.profile_steps > 0:
+        torch.cuda.synchronize(dev)
         eng.profile(True)
         for _ in range(args.profile_steps):
             step()

@@ -39,6 +39,7 @@ SYMBOLS = {
     'cocr_forward': (_I, [_P, _P, _I, _I, _I, _I, _I32P, _P, _I32P, _P]),
     'cocr_ctc_greedy': (_I, [_P, _P, _I, _I, _I, _I32P, _P, _P, _P, _P, _P, _I, _P]),
     'cocr_ctc_beam': (_I, [_P, _P, _I, _I, _I, _I32P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'cocr_set_graph': (_I, [_P, _I]),
     'cocr_set_debug': (_I, [_P, _I]),
     'cocr_debug_tap': (_I, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     'cocr_profile': (_I, [_P, _I]),

@@ -97,6 +97,10 @@ struct cocr_model {
     size_t ctc_cap = 0;
     int lens_cap = 0;
     // debug / profile
+    // hipGraph replay of the forward's launch sequence, keyed by the call's shapes and buffers
+    bool use_graph = false;
+    struct GraphEntry { const void *lines; float *logits; int N, W, dtype; hipStream_t s; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs, graph_seen;
     bool debug = false;
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
@@ -207,6 +211,7 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->d_lens) (void)hipFree(m->d_lens);
     if (m->ctc_lab) (void)hipFree(m->ctc_lab);
     if (m->ctc_val) (void)hipFree(m->ctc_val);
+    for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
@@ -483,6 +488,8 @@ extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipDeviceSynchronize());
     N = std::max(N, m->capN); W = std::max(W, m->capW);
+    for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);     // captured launches point into the old workspace
+    m->graphs.clear(); m->graph_seen.clear();
     free_workspace(m);
     const size_t es = esize(m->dtype);
     int T = W;
@@ -776,14 +783,41 @@ extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, in
     if (in_lens && out_lens)
         for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
     hipStream_t s = (hipStream_t)stream;
-    if (m->dtype == COCR_BF16) {
-        if (line_dtype == COCR_F32) return forward_impl<bf16_t, float>(m, (const float *)lines, N, H, W, logits, s);
-        if (line_dtype == COCR_U8) return forward_impl<bf16_t, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
-    } else {
-        if (line_dtype == COCR_F32) return forward_impl<float, float>(m, (const float *)lines, N, H, W, logits, s);
-        if (line_dtype == COCR_U8) return forward_impl<float, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
+    auto run = [&]() -> int {
+        if (m->dtype == COCR_BF16) {
+            if (line_dtype == COCR_F32) return forward_impl<bf16_t, float>(m, (const float *)lines, N, H, W, logits, s);
+            if (line_dtype == COCR_U8) return forward_impl<bf16_t, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
+        } else {
+            if (line_dtype == COCR_F32) return forward_impl<float, float>(m, (const float *)lines, N, H, W, logits, s);
+            if (line_dtype == COCR_U8) return forward_impl<float, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
+        }
+        return fail(COCR_EINVAL, "line dtype must be COCR_F32 or COCR_U8");
+    };
+    if (!m->use_graph || m->debug || m->profile || s == nullptr) return run();
+    // Launch-bound regime (~120 kernels of 10-40 us per forward): the second identical call captures the launch sequence
+    // into a hipGraph, later identical calls replay it (one host call instead of ~120).
+    auto same = [&](const cocr_model::GraphEntry &g) { return g.lines == lines && g.logits == logits && g.N == N && g.W == W && g.dtype == line_dtype && g.s == s; };
+    for (auto &g : m->graphs)
+        if (same(g)) { HIP_TRY(hipGraphLaunch(g.exec, s)); return COCR_OK; }
+    bool seen = false;
+    for (auto &g : m->graph_seen) seen = seen || same(g);
+    if (!seen || m->vtN != N || m->vtT != cocr_out_len(W, m->hp.subsampling_factor)) {     // first call: plain (also does one-time attribute / zeroing work)
+        m->graph_seen.push_back({lines, logits, N, W, line_dtype, s, nullptr});
+        return run();
     }
-    return fail(COCR_EINVAL, "line dtype must be COCR_F32 or COCR_U8");
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = run();
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return fail(COCR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    if (m->graphs.size() >= 16) { (void)hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
+    m->graphs.push_back({lines, logits, N, W, line_dtype, s, exec});
+    HIP_TRY(hipGraphLaunch(exec, s));
+    return COCR_OK;
 }
 
 // ------------------------------------------------------------------------------------ CTC
@@ -903,5 +937,11 @@ extern "C" int cocr_dev_bench_gemm(int variant, int M, int N, int K, int iters, 
     *us_out = (double)ms * 1e3 / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(O); (void)hipFree(X); (void)hipFree(bias); (void)hipFree(gam);
+    return COCR_OK;
+}
+
+extern "C" int cocr_set_graph(cocr_model *m, int on) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    m->use_graph = on != 0;
     return COCR_OK;
 }

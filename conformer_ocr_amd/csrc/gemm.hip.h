@@ -550,12 +550,98 @@ static inline hipError_t launch_gemm(hipStream_t s, const T *A, int lda, const T
     return launch_stream_cfg<T, 64, 64, Epi>(s, a, epi);
 }
 
-// Row-complete product (N == encoder_dim <= 256) with the fused residual + LayerNorm epilogue: 32 x 256 tiles.
+// ---- row-complete ring kernel: 48 rows x 256 columns per workgroup ------------------------------------------------
+// For the N == encoder_dim <= 256 products with the residual + LayerNorm epilogue.  M = 9600 rows over 256 CUs is
+// 37.5 rows per CU: 48-row workgroups give 200 workgroups = ONE wave of workgroups at one per CU (64-row ones leave 106
+// CUs idle, 32-row ones need two rounds).  4 waves side by side (1 x 4): each wave owns all 48 rows x 64 columns
+// (3 x 4 MFMA tiles: 12 MFMAs per 7 fragment reads).  The A tile is DMA'd as 64 rows (rows >= 48 are never read), the
+// ring is 3 deep (one workgroup per CU: the ring is the latency hiding).
+template <typename T, typename Epi>
+__global__ __launch_bounds__(256) void gemm_rowln48_kernel(GemmArgs<T> p, Epi epi) {
+    constexpr int BMC = 48, BMD = 64, BN = 256, NST = 3;
+    constexpr int ROWB = 128, BK = ROWB / sizeof(T), EPC = 16 / sizeof(T);
+    constexpr int MI = 3, NI = 4;
+    constexpr int PER = BMD / 32 + BN / 32;
+    constexpr int STAGE = (BMD + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = p.M, N = p.N, K = p.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4, swz = r16 & 7;
+    const int m0 = blockIdx.x * BMC;
+    const int nk = K / BK;
+    auto issue = [&](int kt) {
+        unsigned char *st = smem + (kt % NST) * STAGE;
+        const int k0 = kt * BK, lrow = lane >> 3, cpos = lane & 7;
+#pragma unroll
+        for (int i = 0; i < BMD / 32; ++i) {
+            const int rg = wave + 4 * i, row = rg * 8 + lrow;
+            const T *src = p.A + (size_t)min(m0 + row, M - 1) * p.lda + k0 + ((cpos ^ (row & 7)) * EPC);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + rg * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int rg = wave + 4 * i, row = rg * 8 + lrow;
+            const T *src = p.W + (size_t)min(row, N - 1) * p.ldw + k0 + ((cpos ^ (row & 7)) * EPC);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + BMD * ROWB + rg * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();      // at this point tiles 0 .. kt+1 have been issued
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const unsigned char *st = smem + (kt % NST) * STAGE;
+        const unsigned char *sa = st + r16 * ROWB;
+        const unsigned char *sw = st + BMD * ROWB + (wave * 64 + r16) * ROWB;
+#pragma unroll
+        for (int kc = 0; kc < BK / 32; ++kc) {
+            typename FragOf<T>::type a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = lds_frag_swz(sa + i * 16 * ROWB, kc, g, swz, T());
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = lds_frag_swz(sw + j * 16 * ROWB, kc, g, swz, T());
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mma16(b[j], a[i], acc[i][j]);
+        }
+    }
+    __syncthreads();
+    constexpr int RS = BN * 4 + 16;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = 16 * i + r16, n = wave * 64 + 16 * j + 4 * g;
+            const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float r[4];
+            epi.transform(n, v, r);
+            *reinterpret_cast<f32x4 *>(smem + row * RS + n * 4) = (f32x4){r[0], r[1], r[2], r[3]};
+        }
+    __syncthreads();
+    for (int rr = wave * 4; rr < BMC; rr += 16) epi.rows4(m0 + rr, min(M, m0 + BMC), reinterpret_cast<const float *>(smem + rr * RS), RS / 4, lane);
+}
+
+// Row-complete product (N == encoder_dim <= 256) with the fused residual + LayerNorm epilogue.
 template <typename T> static inline bool gemm_rowln_supported(int N) { return N <= 256 && (N & 3) == 0; }
 template <typename T, typename Epi>
 static inline hipError_t launch_gemm_rowln(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, const Epi &epi) {
     GemmArgs<T> a{A, lda, W, ldw, M, N, K};
     constexpr int BK = 128 / (int)sizeof(T);
-    if (K % BK == 0) return launch_ring_cfg<T, 32, 256, 2, Epi>(s, a, epi);
+    if (K % BK == 0) {
+        const size_t lds = (size_t)3 * (64 + 256) * 128;          // >= the 48 x (256*4+16) staged tile
+        auto kern = gemm_rowln48_kernel<T, Epi>;
+        hipError_t e = raise_lds_limit((const void *)kern, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(ceil_div(M, 48)), dim3(256), lds, s, a, epi);
+        return hipGetLastError();
+    }
     return launch_stream_cfg<T, 32, 256, Epi>(s, a, epi);
 }

@@ -95,8 +95,13 @@ class HipRecognizer:
     def reserve(self, n: int, w: int) -> None:
         _lib.check(self.lib.cocr_reserve(self._h, int(n), int(w)))
 
-    def forward(self, lines: torch.Tensor, lens: Sequence[int]) -> Tuple[torch.Tensor, np.ndarray]:
-        """lines: (N,H,W) float32 or uint8 on this device, contiguous.  Returns (logits (N,T,ncls) f32 device, out_lens int32 host)."""
+    def set_graph(self, on: bool) -> None:
+        """hipGraph replay of repeated identical forwards (same input / output buffers): see include/cocr.h."""
+        _lib.check(self.lib.cocr_set_graph(self._h, int(on)))
+
+    def forward(self, lines: torch.Tensor, lens: Sequence[int], out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, np.ndarray]:
+        """lines: (N,H,W) float32 or uint8 on this device, contiguous.  Returns (logits (N,T,ncls) f32 device, out_lens int32 host).
+        `out`: optional preallocated logits buffer (keeps the output address fixed for graph replay)."""
         if not self.ready:
             raise RuntimeError('model not finalized')
         if lines.device != self.device:
@@ -115,7 +120,9 @@ class HipRecognizer:
             raise ValueError('lens must have one entry per line')
         out_lens = np.zeros(N, dtype=np.int32)
         T = self.out_len(W)
-        logits = torch.empty((N, T, self.hp.num_classes), dtype=torch.float32, device=self.device)
+        logits = out if out is not None else torch.empty((N, T, self.hp.num_classes), dtype=torch.float32, device=self.device)
+        if logits.shape != (N, T, self.hp.num_classes) or logits.dtype != torch.float32 or not logits.is_contiguous():
+            raise ValueError('out must be a contiguous float32 (N,T,num_classes) tensor')
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cocr_forward(self._h, C.c_void_p(lines.data_ptr()), ldt, N, H, W,
                                              in_lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(logits.data_ptr()),

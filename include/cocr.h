@@ -119,6 +119,11 @@ int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, int ncls, co
                   int32_t *labels, int32_t *starts, int32_t *ends, float *conf, int32_t *counts,
                   int max_per_line, int beam, void *stream);
 
+/* Launch-overhead control: with graph replay on, the second cocr_forward call with identical (lines, logits, N, W,
+ * dtype, stream) captures its ~120 kernel launches into a hipGraph and later identical calls replay it.  The caller
+ * must then keep `lines` / `logits` at the same addresses (contents may change).  Off by default. */
+int cocr_set_graph(cocr_model *m, int on);
+
 /* Test taps: with debug on, cocr_forward keeps a float32 copy of every stage output
  * ("front.z2", "front.z3", "front.y", "l<i>.ffn1|mhsa|conv|ffn2|out", "l<i>.q|k|v|ctx|glu|dw").
  * cocr_debug_tap copies one to HOST memory; *n_elems receives its element count. */
