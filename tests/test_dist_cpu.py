@@ -1,0 +1,64 @@
+"""The N > 1 path on CPU: world_size 2 over gloo (lines shard as independent units; the only
+collective is the start-up weight broadcast; results gather on rank 0 for reporting)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conformer_ocr_amd import synth
+from conformer_ocr_amd.dist import broadcast_state_dict, bucket_width, gather_strings, shard_batches
+from conformer_ocr_amd.spec import model_state_spec
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        hp = synth.hparams('tiny')
+        spec = {k: v[0] for k, v in model_state_spec(hp).items() if v[1] != 'counter'}
+        state = synth.make_state_dict(hp, seed=11) if rank == 0 else None
+        got = broadcast_state_dict(state, spec, src=0)
+        ref = synth.make_state_dict(hp, seed=11)
+        same = all(np.array_equal(got[k], ref[k]) for k in spec)
+        # sharding: 7 batches over 2 ranks, every batch exactly once
+        mine = shard_batches(7, rank, world)
+        strings = [f'line{b}' for b in mine]
+        gathered = gather_strings(strings, mine, 7)
+        q.put((rank, same, mine, gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world_size_2_broadcast_shard_gather():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)                                   # both ranks hold the root's weights
+    assert sorted(res[0][2] + res[1][2]) == list(range(7))          # disjoint cover
+    assert res[0][3] == [f'line{i}' for i in range(7)] and res[1][3] is None
+
+
+def test_bucket_edges_are_rank_independent():
+    assert [bucket_width(w) for w in (1, 200, 201, 1199, 1200, 2400)] == [200, 200, 400, 1200, 1200, 2400]
+    # the padded width of a line (hence its logits: SURVEY 0.6) depends on the line alone
+    widths = [417, 640, 903, 1111]
+    assert [bucket_width(w) for w in widths] == [bucket_width(w) for w in reversed(widths)][::-1]

@@ -1,0 +1,155 @@
+"""CPU-side checks of the host layer: the C-ABI library loads and exports every symbol include/cocr.h
+declares, argument validation mirrors the reference constructors, the codec stand-in, the host class
+surface and its loaders.  No compute call is made (no GPU here)."""
+import ctypes as C
+import io
+import json
+import os
+import re
+import tarfile
+
+import numpy as np
+import pytest
+import torch
+
+from conformer_ocr_amd import _lib, synth
+from conformer_ocr_amd.codec import PytorchCodec, ascii_codec
+from conformer_ocr_amd.pred import PytorchRecognitionModel, save_safetensors
+from conformer_ocr_amd.spec import HParams, model_state_spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPS = dict(input_dropout_p=0.1, feed_forward_dropout_p=0.1, attention_dropout_p=0.1, conv_dropout_p=0.1)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'cocr.h')).read()
+    declared = set(re.findall(r'\b(cocr_[a-z_0-9]+)\s*\(', header))
+    assert declared, 'no declarations found'
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.cocr_version().startswith(b'cocr-hip')
+
+
+def test_out_len_entry_point_matches_calc_length():
+    lib = _lib.load()
+    for w, f, want in [(1200, 4, 300), (512, 4, 128), (300, 4, 75), (37, 4, 10), (96, 8, 12), (1, 4, 1), (2400, 4, 600)]:
+        assert lib.cocr_out_len(w, f) == want
+
+
+def _hp(**kw):
+    base = dict(num_classes=11, height=16, encoder_dim=32, num_encoder_layers=1, num_attention_heads=4,
+                feed_forward_expansion_factor=4, conv_expansion_factor=2, conv_kernel_size=7, half_step_residual=1,
+                subsampling_conv_channels=8, subsampling_factor=4)
+    base.update(kw)
+    return _lib.HParamsC(**base)
+
+
+def test_create_validates_like_the_reference_constructors():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.cocr_create(C.byref(_hp()), 0, C.byref(h)) == 0
+    buf = C.create_string_buffer(1 << 16)
+    n = lib.cocr_missing_tensors(h, buf, len(buf))
+    one_layer = HParams(**{**synth.CONFIGS['tiny'], 'num_encoder_layers': 1})
+    assert n == len([k for k in model_state_spec(one_layer) if not k.endswith('num_batches_tracked')]) == 48
+    lib.cocr_destroy(h)
+    for bad, msg in [(dict(num_attention_heads=5), b'num_heads'), (dict(conv_kernel_size=8), b'odd'),
+                     (dict(conv_expansion_factor=3), b'expansion_factor 2'), (dict(subsampling_factor=6), b'power of 2')]:
+        rc = lib.cocr_create(C.byref(_hp(**bad)), 0, C.byref(h))
+        assert rc == _lib.EINVAL and msg in lib.cocr_last_error()
+        with pytest.raises(ValueError):
+            _lib.check(rc)
+
+
+def test_set_tensor_rejects_unknown_keys_and_compute_needs_finalize():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.cocr_create(C.byref(_hp()), 0, C.byref(h)) == 0
+    a = np.zeros(4, np.float32)
+    shape = (C.c_int64 * 1)(4)
+    assert lib.cocr_set_tensor(h, b'encoder.nonsense', a.ctypes.data_as(C.c_void_p), _lib.F32, 1, shape) == _lib.EINVAL
+    assert lib.cocr_set_tensor(h, b'encoder.layers.0.sequential.2.module.sequential.5.num_batches_tracked',
+                               a.ctypes.data_as(C.c_void_p), _lib.I64, 0, shape) == 0
+    lens = (C.c_int32 * 1)(40)
+    assert lib.cocr_forward(h, C.c_void_p(16), _lib.F32, 1, 16, 40, lens, C.c_void_p(16), lens, None) == _lib.ESTATE
+    lib.cocr_destroy(h)
+
+
+def test_codec_roundtrip_and_longest_match():
+    c = PytorchCodec({'a': [1], 'b': [2], 'ch': [3, 4], 'c': [3]})
+    assert c.max_label == 4 and len(c) == 4 and c.is_valid
+    assert c.encode('abchc') == [1, 2, 3, 4, 3]
+    recs = [(1, 0, 1, 0.9), (3, 2, 3, 0.5), (4, 4, 4, 0.7), (3, 6, 6, 0.8), (9, 7, 7, 0.1)]
+    assert c.decode(recs) == [('a', 0, 1, 0.9), ('c', 2, 4, 0.7), ('h', 2, 4, 0.7), ('c', 6, 6, 0.8)]   # label 9 is skipped
+    assert ''.join(x[0] for x in ascii_codec(11).decode([(1, 0, 0, 1.0), (10, 1, 1, 1.0)])) == '!*'
+    with pytest.raises(ValueError):
+        PytorchCodec({'a': [0]})
+
+
+def _net(hp, **kw):
+    return PytorchRecognitionModel(**hp.as_dict(), **DROPS, codec=ascii_codec(hp.num_classes), **kw)
+
+
+def test_host_class_surface_matches_the_reference():
+    hp = synth.hparams('tiny')
+    net = _net(hp, some_training_only_kwarg=3)             # unknown kwargs are ignored (pred.py:69)
+    assert set(net.nn.keys()) == {'encoder', 'decoder'}
+    assert (net.height, net.channels, net.width) == (16, 1, 0)
+    for name in ('forward', 'predict', 'predict_string', 'predict_labels', 'load_safetensors', 'load_checkpoint'):
+        assert callable(getattr(net, name))
+    spec = model_state_spec(hp)
+    sd = net.nn.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    assert all(tuple(sd[k].shape) == spec[k][0] for k in spec)
+    # no layer of the network is a torch compute module: only parameter holders and the decoder's parameters
+    assert not any(isinstance(m, (torch.nn.Conv2d, torch.nn.LayerNorm, torch.nn.BatchNorm1d)) for m in net.modules())
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net.forward(torch.zeros(1, 1, 16, 40), torch.tensor([40]))
+    with pytest.raises(TypeError):
+        net.forward(torch.zeros(1, 1, 16, 40))
+
+
+def test_safetensors_and_checkpoint_loaders(tmp_path):
+    hp = synth.hparams('tiny')
+    state = synth.make_state_dict(hp, seed=3)
+    net = _net(hp)
+    net.nn.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    p = tmp_path / 'model.tar'
+    save_safetensors(net, p)
+    back = PytorchRecognitionModel.load_safetensors(p)
+    assert not back.training and back.codec.c2l == net.codec.c2l
+    for k, v in back.nn.state_dict().items():
+        assert torch.equal(v, net.nn.state_dict()[k]), k
+    # archive without hyper-parameters -> the reference's ValueError (pred.py:190-191)
+    bad = tmp_path / 'bad.tar'
+    with tarfile.open(bad, 'w') as tf:
+        data = json.dumps({'codec': {'a': [1]}}).encode()
+        ti = tarfile.TarInfo('metadata.json'); ti.size = len(data); tf.addfile(ti, io.BytesIO(data))
+    with pytest.raises(ValueError, match='hyperparameters'):
+        PytorchRecognitionModel.load_safetensors(bad)
+    # lightning-style checkpoint: keys nn.encoder.* / nn.decoder.*, hyper_parameters with training-only extras
+    ck = {'state_dict': {'nn.' + k: torch.from_numpy(np.asarray(v)) for k, v in state.items()},
+          'hyper_parameters': {**hp.as_dict(), **DROPS, 'lr': 3e-4, 'batch_size': 32},
+          'TextLineDataModule': {'codec': {'a': [1], 'b': [2]}}}
+    pth = tmp_path / 'ckpt.ckpt'
+    torch.save(ck, pth)
+    net2 = PytorchRecognitionModel.load_checkpoint(pth)
+    assert torch.equal(net2.nn.state_dict()['decoder.weight'], torch.from_numpy(state['decoder.weight']))
+    torch.save({'state_dict': {}}, pth)
+    with pytest.raises(ValueError, match='data module state'):
+        PytorchRecognitionModel.load_checkpoint(pth)
+    torch.save({'state_dict': {}, 'TextLineDataModule': {'codec': {'a': [1]}}}, pth)
+    with pytest.raises(ValueError, match='No hyperparameters'):
+        PytorchRecognitionModel.load_checkpoint(pth)
+
+
+def test_synthetic_generators_are_deterministic():
+    hp = synth.hparams('tiny')
+    a, b = synth.make_state_dict(hp, 5), synth.make_state_dict(hp, 5)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert not np.array_equal(a['decoder.weight'], synth.make_state_dict(hp, 6)['decoder.weight'])
+    img, lens = synth.make_lines(3, 16, 64, seed=2, widths=[64, 37, 50])
+    assert img.shape == (3, 1, 16, 64) and img.dtype == np.float32 and (img[1, :, :, 37:] == 0).all()
+    np.testing.assert_array_equal(synth.lines_u8(img).astype(np.float32) / np.float32(255.0), img)
