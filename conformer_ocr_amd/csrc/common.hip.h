@@ -57,15 +57,31 @@ template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
+// Wave-wide reductions by DPP (data-parallel primitives: a lane permutation folded into the VALU op), result
+// uniform in all 64 lanes.  __shfl_xor compiles to ds_bpermute (an LDS-crossbar round trip per step: a 6-step
+// dependent chain cost ~500 cycles per reduction in the LayerNorm epilogues).  Steps: xor 1, xor 2 (quad_perm),
+// half-row mirror, row mirror -> every lane holds its 16-lane row's result; row_bcast15 into rows 1,3, row_bcast31
+// into rows 2,3 -> lane 63 holds the wave's result; v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f32(float v, float old) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1, 0xF>(v, 0.f);      // quad_perm(1,0,3,2)
+    v += dpp_f32<0x4E, 0xF>(v, 0.f);      // quad_perm(2,3,0,1)
+    v += dpp_f32<0x141, 0xF>(v, 0.f);     // row_half_mirror
+    v += dpp_f32<0x140, 0xF>(v, 0.f);     // row_mirror
+    v += dpp_f32<0x142, 0xA>(v, 0.f);     // row_bcast15 -> rows 1, 3
+    v += dpp_f32<0x143, 0xC>(v, 0.f);     // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -40,7 +40,13 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
     const int nchunks = FF / 128;
     const int lrow = lane >> 3, cpos = lane & 7;
 
-    for (int i = tid; i < FF; i += 512) b1s[i] = b1[i];     // before any DMA is in flight (its wait would drain them)
+    // residual rows of this wave's share of the LayerNorm epilogue: requested first, consumed last
+    typename Epi::Rows4 xr[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) xr[it] = epi.rows4_load(m0 + wave * 4 + 32 * it, M, lane);
+    // b1 -> LDS by DMA as well (FF * 4 bytes = FF / 256 wave-instructions of 1 KiB)
+    for (int i = wave; i < FF / 256; i += 8)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b1 + i * 256 + lane * 4), (lds_ptr_t)(reinterpret_cast<unsigned char *>(b1s) + i * 1024), 16, 0, 0);
 
     // operand tile: DK panels x 8 row groups = 32 wave-instructions, rows clamped at M-1
 #pragma unroll
@@ -69,7 +75,6 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
     };
     issue_pair(0, std::integral_constant<int, 0>{});
     issue_pair(0, std::integral_constant<int, 1>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // b1s written before the first barrier
 
     f32x4 acc1[2][2], acc2[2][4];                           // wave tile 32 x 32 of the hidden chunk; 32 rows x (2 halves x 32 columns) of the output
 #pragma unroll
@@ -77,6 +82,16 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int npairs = nchunks * 4;
+    // The wave's 32 operand rows stay in registers for the whole kernel (2 x 8 fragments = 64 VGPRs): the first product then
+    // reads only weight fragments from LDS.  The operand DMAs were issued before the two weight pairs (4 * PER instructions).
+    wait_vmcnt<4 * PER>();
+    __builtin_amdgcn_s_barrier();
+    bf16x8 xa[2][2 * DK];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2 * DK; ++kk)
+            xa[i][kk] = lds_frag_swz(xs + (kk >> 1) * PANEL + (wm * 32 + 16 * i + r16) * 128, kk & 1, g, swz, T());
 
     auto step = [&](int c, auto KP) {
         constexpr int kp = decltype(KP)::value;
@@ -101,18 +116,15 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                const unsigned char *sa = xs + (kt + h) * PANEL + (wm * 32 + r16) * 128;
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
-                    bf16x8 a[2], b[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) a[i] = lds_frag_swz(sa + i * 16 * 128, kc, g, swz, T());
+                    bf16x8 b[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) b[j] = lds_frag_swz(sw + j * 16 * 128, kc, g, swz, T());
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc1[i][j] = mma16(b[j], a[i], acc1[i][j]);
+                        for (int j = 0; j < 2; ++j) acc1[i][j] = mma16(b[j], xa[i][2 * (kt + h) + kc], acc1[i][j]);
                 }
             } else {
                 const unsigned char *sa = hs + (kp - 2) * PANEL + (wm * 32 + r16) * 128;
@@ -168,10 +180,14 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
         }
     }
     __syncthreads();
-    for (int rr = wave * 4; rr < 64; rr += 32) epi.rows4(m0 + rr, M, reinterpret_cast<const float *>(ring + rr * RS), RS / 4, lane);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int rr = wave * 4 + 32 * it;
+        epi.rows4(m0 + rr, M, reinterpret_cast<const float *>(ring + rr * RS), RS / 4, lane, xr[it]);
+    }
 }
 
-template <typename Epi> static inline bool ffn_fused_supported(int D, int FF) { return D == 256 && FF % 128 == 0 && FF >= 128; }
+template <typename Epi> static inline bool ffn_fused_supported(int D, int FF) { return D == 256 && FF % 256 == 0 && FF >= 256; }
 
 template <typename Epi, int MODE = 0>
 static inline hipError_t launch_ffn_fused(hipStream_t s, const bf16_t *xn, const bf16_t *W1, const float *b1, const bf16_t *W2, int M, int D, int FF,

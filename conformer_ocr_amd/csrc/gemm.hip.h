@@ -188,8 +188,26 @@ template <typename T, int NV> struct EpiResidualLN {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = alpha * (v[i] + (n + i < N ? bias[n + i] : 0.f));
     }
-    // rows m0 .. m0+3 (row r valid if m0 + r < M); staged row r at `staged + r * rs_floats`
+    // The residual rows can be fetched long before the accumulators are ready (kernel prologue): the epilogue then has no
+    // global-load latency left in it.  rows m0 .. m0+3; clamped addresses, rows >= M are discarded at the stores.
+    struct Rows4 { f32x4 v[4][NV]; };
+    __device__ __forceinline__ Rows4 rows4_load(int m0, int M, int lane) const {
+        const int nchunk = D >> 2;
+        Rows4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cc = min(lane + 64 * v, nchunk - 1);
+                p.v[r][v] = *reinterpret_cast<const f32x4 *>(x + (size_t)min(m0 + r, M - 1) * D + 4 * cc);
+            }
+        return p;
+    }
     __device__ __forceinline__ void rows4(int m0, int M, const float *staged, int rs_floats, int lane) const {
+        rows4(m0, M, staged, rs_floats, lane, rows4_load(m0, M, lane));
+    }
+    // rows m0 .. m0+3 (row r valid if m0 + r < M); staged row r at `staged + r * rs_floats`; xr = rows4_load(m0, M, lane)
+    __device__ __forceinline__ void rows4(int m0, int M, const float *staged, int rs_floats, int lane, const Rows4 &xr) const {
         const int nchunk = D >> 2;
         const float inv_d = 1.0f / (float)D;
         f32x4 xv[4][NV];
@@ -200,11 +218,9 @@ template <typename T, int NV> struct EpiResidualLN {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int c = lane + 64 * v;
-                // unconditional, clamped loads + selects: a branch around each load would serialise the 4 rows' round trips
                 const int cc = min(c, nchunk - 1);
                 f32x4 t = *reinterpret_cast<const f32x4 *>(staged + r * rs_floats + 4 * cc);
-                const f32x4 xr = *reinterpret_cast<const f32x4 *>(x + (size_t)min(m0 + r, M - 1) * D + 4 * cc);
-                if (has_resid) t += xr;
+                if (has_resid) t += xr.v[r][v];
                 if (c >= nchunk) t = (f32x4){0, 0, 0, 0};
                 xv[r][v] = t;
                 s[r] += t[0] + t[1] + t[2] + t[3];
@@ -586,6 +602,10 @@ __global__ __launch_bounds__(256) void gemm_rowln48_kernel(GemmArgs<T> p, Epi ep
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + BMD * ROWB + rg * 1024), 16, 0, 0);
         }
     };
+    // residual rows of this wave's share of the LayerNorm epilogue: requested first, consumed last
+    typename Epi::Rows4 xr[BMC / 16];
+#pragma unroll
+    for (int it = 0; it < BMC / 16; ++it) xr[it] = epi.rows4_load(m0 + wave * 4 + 16 * it, min(M, m0 + BMC), lane);
     issue(0);
     if (nk > 1) issue(1);
     f32x4 acc[MI][NI];
@@ -626,7 +646,11 @@ __global__ __launch_bounds__(256) void gemm_rowln48_kernel(GemmArgs<T> p, Epi ep
             *reinterpret_cast<f32x4 *>(smem + row * RS + n * 4) = (f32x4){r[0], r[1], r[2], r[3]};
         }
     __syncthreads();
-    for (int rr = wave * 4; rr < BMC; rr += 16) epi.rows4(m0 + rr, min(M, m0 + BMC), reinterpret_cast<const float *>(smem + rr * RS), RS / 4, lane);
+#pragma unroll
+    for (int it = 0; it < BMC / 16; ++it) {
+        const int rr = wave * 4 + 16 * it;
+        epi.rows4(m0 + rr, min(M, m0 + BMC), reinterpret_cast<const float *>(smem + rr * RS), RS / 4, lane, xr[it]);
+    }
 }
 
 // Row-complete product (N == encoder_dim <= 256) with the fused residual + LayerNorm epilogue.

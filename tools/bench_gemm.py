@@ -8,7 +8,7 @@ lib = _lib.load()
 fn = lib.cocr_dev_bench_gemm
 fn.restype = C.c_int
 fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-shapes = {'ffn_up': (9600, 1024, 256), 'ffn_down': (9600, 256, 1024), 'proj256': (9600, 256, 256), 'qkv': (9600, 768, 256),
+shapes = {'ffn128': (9600, 128, 256), 'ffn256': (9600, 256, 256), 'ffn512': (9600, 512, 256), 'ffn_up': (9600, 1024, 256), 'ffn2048': (9600, 2048, 256), 'ffn_down': (9600, 256, 1024), 'proj256': (9600, 256, 256), 'qkv': (9600, 768, 256),
           'glu': (9600, 512, 256), 'front_pw': (230400, 256, 256), 'front_out': (9600, 256, 6144)}
 plain = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 30, 31, 20, 21]
 if len(sys.argv) > 1:
