@@ -913,11 +913,9 @@ extern "C" int cocr_dev_bench_gemm(int variant, int M, int N, int K, int iters, 
             case 9: return resid ? launch_stream_cfg<T, 64, 64>(0, a, er) : launch_stream_cfg<T, 64, 64>(0, a, eh);
             case 30: return launch_ring_cfg<T, 128, 128, 2>(0, a, en);
             case 31: return launch_ring_cfg<T, 64, 64, 3>(0, a, en);
-            case 40: case 41: case 42: {   // fused FFN on (M, D=256, FF=N): A = xn [M][256], W = W1 [N][256], O reused as W2 [256][N]
+            case 40: {   // fused FFN on (M, D=256, FF=N): A = xn [M][256], W = W1 [N][256], O reused as W2 [256][N]
                 EpiResidualLN<T, 1> e{X, 256, bias, 0.5f, 256, 1, gam, gam, nullptr, nullptr, (T *)A};
-                if (variant == 40) return launch_ffn_fused<EpiResidualLN<T, 1>, 0>(0, (const T *)A, (const T *)W, bias, (const T *)O, M, 256, N, e);
-                if (variant == 41) return launch_ffn_fused<EpiResidualLN<T, 1>, 1>(0, (const T *)A, (const T *)W, bias, (const T *)O, M, 256, N, e);
-                return launch_ffn_fused<EpiResidualLN<T, 1>, 2>(0, (const T *)A, (const T *)W, bias, (const T *)O, M, 256, N, e);
+                return launch_ffn_fused<EpiResidualLN<T, 1>>(0, (const T *)A, (const T *)W, bias, (const T *)O, M, 256, N, e);
             }
             case 20: launch_layernorm<T>(0, X, M, K, gam, gam, nullptr, nullptr, nullptr, (T *)A); return hipGetLastError();
             case 21: launch_layernorm<T>(0, X, M, K, gam, gam, X, gam, gam, (T *)A); return hipGetLastError();
