@@ -95,6 +95,8 @@ struct cocr_model {
     int32_t *ctc_lab = nullptr;
     float *ctc_val = nullptr;
     size_t ctc_cap = 0;
+    int32_t *beam_bp = nullptr;
+    size_t beam_cap = 0;
     int lens_cap = 0;
     // debug / profile
     // hipGraph replay of the forward's launch sequence, keyed by the call's shapes and buffers
@@ -211,6 +213,7 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->d_lens) (void)hipFree(m->d_lens);
     if (m->ctc_lab) (void)hipFree(m->ctc_lab);
     if (m->ctc_val) (void)hipFree(m->ctc_val);
+    if (m->beam_bp) (void)hipFree(m->beam_bp);
     for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
@@ -856,9 +859,30 @@ extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T,
     return COCR_OK;
 }
 
-extern "C" int cocr_ctc_beam(cocr_model *, const float *, int, int, int, const int32_t *, int32_t *, int32_t *, int32_t *, float *, int32_t *,
-                             int, int, void *) {
-    return fail(COCR_EUNSUPPORTED, "cocr_ctc_beam: not built yet");
+extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, int ncls, const int32_t *out_lens, int32_t *labels,
+                             int32_t *starts, int32_t *ends, float *conf, int32_t *counts, int max_per_line, int beam, void *stream) {
+    if (!m || !logits || !out_lens || !labels || !starts || !ends || !conf || !counts) return fail(COCR_EINVAL, "null argument");
+    if (N < 1 || T < 1 || ncls < 2 || max_per_line < 1) return fail(COCR_EINVAL, "empty problem");
+    if (beam < 1 || beam > COCR_BEAM_MAX) return fail(COCR_EINVAL, "beam must be in 1..%d", COCR_BEAM_MAX);
+    if (ncls > 65535) return fail(COCR_EUNSUPPORTED, "more than 65535 classes");
+    const size_t lds = ((size_t)ncls + (size_t)beam * ncls) * 4 + COCR_BEAM_MAX * (11 * 4 + 2 * 8) + 64;
+    if (lds > 150 * 1024) return fail(COCR_EUNSUPPORTED, "beam x classes too large for the LDS candidate table");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = upload_lens(m, out_lens, N, s);
+    if (rc) return rc;
+    const size_t need = (size_t)N * T * (COCR_BEAM_MAX + 1);
+    if (need > m->beam_cap) {
+        if (m->beam_bp) (void)hipFree(m->beam_bp);
+        HIP_TRY(hipMalloc((void **)&m->beam_bp, need * 4));
+        m->beam_cap = need;
+    }
+    HIP_TRY(raise_lds_limit((const void *)ctc_beam_kernel, lds));
+    ProfScope ps(m, s, FAM_BEAM);
+    hipLaunchKernelGGL(ctc_beam_kernel, dim3(N), dim3(64), lds, s, logits, T, ncls, m->d_lens, beam, labels, starts, ends, conf, counts,
+                       max_per_line, m->beam_bp, reinterpret_cast<float *>(m->beam_bp + (size_t)N * T * COCR_BEAM_MAX));
+    LAUNCH_CHECK();
+    return COCR_OK;
 }
 
 // ------------------------------------------------------------------------------------ kernel micro-benchmarks (development hook)

@@ -73,3 +73,161 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(int T, const int32_t *
     }
     if (lane == 0) counts[n] = emitted;
 }
+
+// ---- prefix beam search ------------------------------------------------------------------------------------
+// Semantics: oracle/ctc_ref.py::beam_decoder (kraken.lib.ctc_decoder.beam_decoder's algorithm on log-softmax(logits); the
+// reference itself never calls a beam decoder).  One wave per line; per frame:
+//   1. lp = log_softmax(logits[t]) (lanes stride the classes);
+//   2. candidates: every live prefix i stays (p_b += total + lp[0]; p_nb += p_nb + lp[last]) or is extended by s >= 1
+//      (p_nb = (s == last ? p_b : total) + lp[s]); an extension whose label sequence equals another live prefix q is folded
+//      into q's stay candidate (prefix identity = 64-bit rolling hash of the labels); logaddexp = max + log1p(exp(-|d|));
+//   3. the `beam` best candidates by logaddexp(p_b, p_nb) survive; ties keep creation order (position i*C + s; a folded
+//      candidate takes the smaller of the two positions and the start frame of that creator);
+//   4. back-pointers (parent, appended label) per frame and prefix let one lane rebuild the best prefix with the frames at
+//      which its labels were appended; ends / confidences follow the oracle's post-pass.
+#define COCR_BEAM_MAX 32
+
+__device__ __forceinline__ float lse2(float a, float b) {
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float m = fmaxf(a, b);
+    return m + log1pf(expf(-fabsf(a - b)));
+}
+
+__global__ __launch_bounds__(64) void ctc_beam_kernel(const float *__restrict__ logits, int T, int C, const int32_t *__restrict__ lens, int beam,
+                                                      int32_t *__restrict__ labels, int32_t *__restrict__ starts, int32_t *__restrict__ ends,
+                                                      float *__restrict__ conf, int32_t *__restrict__ counts, int max_per_line,
+                                                      int32_t *__restrict__ bp_all, float *__restrict__ logz_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char beam_smem[];
+    unsigned long long *hash = reinterpret_cast<unsigned long long *>(beam_smem);      // 8-byte aligned arrays first
+    unsigned long long *nhash = hash + COCR_BEAM_MAX;
+    float *pb = reinterpret_cast<float *>(nhash + COCR_BEAM_MAX), *pnb = pb + COCR_BEAM_MAX;   // live prefixes
+    float *npb = pnb + COCR_BEAM_MAX, *npnb = npb + COCR_BEAM_MAX;   // next frame
+    float *spb = npnb + COCR_BEAM_MAX, *spnb = spb + COCR_BEAM_MAX;  // stay candidates
+    float *mval = spnb + COCR_BEAM_MAX;                              // folded extension score per live prefix
+    int *mpos = reinterpret_cast<int *>(mval + COCR_BEAM_MAX);       // ... and its position
+    int *last = mpos + COCR_BEAM_MAX, *nlast = last + COCR_BEAM_MAX;
+    int *sel = nlast + COCR_BEAM_MAX;                                // selected positions of this frame
+    float *lp = reinterpret_cast<float *>(sel + COCR_BEAM_MAX);      // [C]
+    float *cand = lp + C;                                            // [beam][C] candidate scores (-inf = none / taken)
+
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int len = min(max(lens[n], 0), T);
+    const float *lg = logits + (size_t)n * T * C;
+    int32_t *bp = bp_all + (size_t)n * T * COCR_BEAM_MAX;            // (parent << 16) | label, per frame and rank
+    float *logz = logz_all + (size_t)n * T;
+    if (lane == 0) { pb[0] = 0.f; pnb[0] = -INFINITY; last[0] = 0; hash[0] = 1469598103934665603ull; }
+    int nb = 1;
+    for (int t = 0; t < len; ++t) {
+        // 1. log-softmax of the frame
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lg[(size_t)t * C + c]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int c = lane; c < C; c += 64) sm += expf(lg[(size_t)t * C + c] - mx);
+        const float lz = mx + logf(wave_sum(sm));
+        for (int c = lane; c < C; c += 64) lp[c] = (lg[(size_t)t * C + c] - mx) - (lz - mx);
+        if (lane == 0) logz[t] = lz;
+        if (lane < COCR_BEAM_MAX) { mval[lane] = -INFINITY; mpos[lane] = 0x7fffffff; }
+        __syncthreads();
+        // 2. candidates
+        for (int i = 0; i < nb; ++i) {
+            const float p_b = pb[i], p_nb = pnb[i], tot = lse2(p_b, p_nb);
+            const int li = last[i];
+            const unsigned long long hi = hash[i];
+            for (int c = lane; c < C; c += 64) {
+                float e = -INFINITY;
+                if (c == 0) {
+                    spb[i] = tot + lp[0];
+                    spnb[i] = li > 0 ? p_nb + lp[li] : -INFINITY;
+                } else {
+                    e = (c == li ? p_b : tot) + lp[c];
+                    if (e > -INFINITY) {
+                        const unsigned long long hc = hi * 1099511628211ull + (unsigned long long)(c + 1);
+                        for (int q = 0; q < nb; ++q)
+                            if (q != i && hash[q] == hc) { mval[q] = e; mpos[q] = i * C + c; e = -INFINITY; break; }
+                    }
+                }
+                cand[(size_t)i * C + c] = e;
+            }
+        }
+        __syncthreads();
+        if (lane < nb) {      // stay candidates, with a folded extension if there is one
+            const float s_nb = lse2(spnb[lane], mval[lane]);
+            spnb[lane] = s_nb;
+            cand[(size_t)lane * C] = lse2(spb[lane], s_nb);
+        }
+        __syncthreads();
+        // 3. the `beam` best by (score desc, position asc); a stay candidate's position is min(i*C, folded position)
+        int nsel = 0;
+        for (int r = 0; r < beam; ++r) {
+            float best = -INFINITY;
+            int bpos = 0x7fffffff, bidx = -1;
+            for (int i = 0; i < nb; ++i)
+                for (int c = lane; c < C; c += 64) {
+                    const float v = cand[(size_t)i * C + c];
+                    const int pos = c == 0 ? min(i * C, mpos[i]) : i * C + c;
+                    if (v > best || (v == best && v > -INFINITY && pos < bpos)) { best = v; bpos = pos; bidx = i * C + c; }
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int op = __shfl_xor(bpos, o, 64), oi = __shfl_xor(bidx, o, 64);
+                if (ov > best || (ov == best && op < bpos)) { best = ov; bpos = op; bidx = oi; }
+            }
+            if (best == -INFINITY) break;
+            if (lane == 0) { sel[r] = bidx; cand[bidx] = -INFINITY; }
+            ++nsel;
+            __syncthreads();
+        }
+        // 4. next beam + back-pointers
+        if (lane < nsel) {
+            const int idx = sel[lane], i = idx / C, c = idx - i * C;
+            if (c == 0) {
+                npb[lane] = spb[i]; npnb[lane] = spnb[i]; nlast[lane] = last[i]; nhash[lane] = hash[i];
+                const int mp = mpos[i];
+                bp[(size_t)t * COCR_BEAM_MAX + lane] = mp < i * C ? (((mp / C) << 16) | (mp % C)) : (i << 16);   // first creator
+            } else {
+                npb[lane] = -INFINITY; npnb[lane] = (c == last[i] ? pb[i] : lse2(pb[i], pnb[i])) + lp[c]; nlast[lane] = c;
+                nhash[lane] = hash[i] * 1099511628211ull + (unsigned long long)(c + 1);
+                bp[(size_t)t * COCR_BEAM_MAX + lane] = (i << 16) | c;
+            }
+        }
+        __syncthreads();
+        if (lane < nsel) { pb[lane] = npb[lane]; pnb[lane] = npnb[lane]; last[lane] = nlast[lane]; hash[lane] = nhash[lane]; }
+        nb = nsel;
+        __syncthreads();
+    }
+    // ---- best prefix: walk the back-pointers (one lane), then ends / confidences in parallel over the labels
+    __shared__ int s_cnt;
+    int32_t *olab = labels + (size_t)n * max_per_line, *ost = starts + (size_t)n * max_per_line;
+    if (lane == 0) {
+        int cnt = 0, e = 0;
+        for (int t = len - 1; t >= 0; --t) {
+            const int v = bp[(size_t)t * COCR_BEAM_MAX + e];
+            if (v & 0xffff) ++cnt;
+            e = v >> 16;
+        }
+        s_cnt = cnt;
+        int k = cnt;
+        e = 0;
+        for (int t = len - 1; t >= 0; --t) {
+            const int v = bp[(size_t)t * COCR_BEAM_MAX + e];
+            if (v & 0xffff) { --k; if (k < max_per_line) { olab[k] = v & 0xffff; ost[k] = t; } }
+            e = v >> 16;
+        }
+        counts[n] = cnt;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const int cnt = min(s_cnt, max_per_line);
+    for (int k = lane; k < cnt; k += 64) {
+        const int c = olab[k], s = ost[k], limit = k + 1 < cnt ? ost[k + 1] : len;
+        int e = s;
+        while (e + 1 < limit && lg[(size_t)(e + 1) * C + c] > lg[(size_t)(e + 1) * C]) ++e;
+        float mxp = -INFINITY;
+        for (int t = s; t <= e; ++t) mxp = fmaxf(mxp, lg[(size_t)t * C + c] - logz[t]);
+        ends[(size_t)n * max_per_line + k] = e;
+        conf[(size_t)n * max_per_line + k] = expf(mxp);
+    }
+}
