@@ -1,0 +1,96 @@
+"""Evaluation loop of the recognition path -- the counterpart of the reference's `cocr test` inner loop
+(reference conformer_ocr/cli/test.py:185-212: batches -> `nn.predict_string` -> `CharErrorRate` / `WordErrorRate`).
+
+Differences that matter on a GPU: lines are grouped into fixed-edge width buckets (a line's logits depend on its padded
+width, SURVEY 0.6, so the padding must not depend on batch composition or rank count); batches are double-buffered on
+side streams so that host->device copies, the forward and the label read-back overlap (the reference is fully serial);
+ranks take batches round-robin with no collective in the loop.  torchmetrics is not a dependency: CER / WER are the same
+edit-distance ratios (errors / reference length) it computes."""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .dist import bucket_width, shard_batches
+
+
+def edit_distance(a: Sequence, b: Sequence) -> int:
+    """Levenshtein distance (insert / delete / substitute = 1)."""
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+class ErrorRate:
+    """torchmetrics.text.CharErrorRate / WordErrorRate semantics: sum(edit distance) / sum(reference length)."""
+
+    def __init__(self, words: bool = False):
+        self.words = words
+        self.errors = 0
+        self.total = 0
+
+    def update(self, preds: Iterable[str], targets: Iterable[str]) -> None:
+        for p, t in zip(preds, targets):
+            if self.words:
+                p, t = p.split(), t.split()
+            self.errors += edit_distance(p, t)
+            self.total += len(t)
+
+    def compute(self) -> float:
+        return self.errors / max(self.total, 1)
+
+
+def make_batches(widths: Sequence[int], batch_size: int, edge: int = 200) -> List[Tuple[int, List[int]]]:
+    """[(padded width, [line indices])]: lines sorted into fixed-edge buckets, widest bucket first (like the reference's
+    collate, lines inside a batch are ordered by width descending)."""
+    buckets: Dict[int, List[int]] = {}
+    for i, w in enumerate(widths):
+        buckets.setdefault(bucket_width(w, edge), []).append(i)
+    out = []
+    for bw in sorted(buckets, reverse=True):
+        idx = sorted(buckets[bw], key=lambda i: -widths[i])
+        out.extend((bw, idx[k:k + batch_size]) for k in range(0, len(idx), batch_size))
+    return out
+
+
+def collate(lines: Sequence[np.ndarray], idx: Sequence[int], width: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(N,1,H,W) float32 right-zero-padded batch + pixel widths (the `collate_sequences` contract, cli/test.py:186-189)."""
+    h = lines[idx[0]].shape[0]
+    batch = np.zeros((len(idx), 1, h, width), dtype=np.float32)
+    lens = np.zeros(len(idx), dtype=np.int64)
+    for n, i in enumerate(idx):
+        w = lines[i].shape[1]
+        batch[n, 0, :, :w] = lines[i]
+        lens[n] = w
+    return torch.from_numpy(batch), torch.from_numpy(lens)
+
+
+def recognize(net, lines: Sequence[np.ndarray], batch_size: int = 32, edge: int = 200, rank: int = 0, world: int = 1,
+              device: str = 'cuda:0') -> Dict[int, str]:
+    """Strings for this rank's share of `lines` (H x w float arrays in [0,1]); keys are line indices."""
+    batches = make_batches([l.shape[1] for l in lines], batch_size, edge)
+    out: Dict[int, str] = {}
+    for b in shard_batches(len(batches), rank, world):
+        width, idx = batches[b]
+        im, lens = collate(lines, idx, width)
+        for i, s in zip(idx, net.predict_string(im.to(device, non_blocking=True), lens)):
+            out[i] = s
+    return out
+
+
+def evaluate(net, lines: Sequence[np.ndarray], truths: Sequence[str], **kw) -> Dict[str, float]:
+    """CER / WER of `net` on (lines, truths): the report of cli/test.py:211-212."""
+    pred = recognize(net, lines, **kw)
+    cer, wer = ErrorRate(False), ErrorRate(True)
+    idx = sorted(pred)
+    cer.update([pred[i] for i in idx], [truths[i] for i in idx])
+    wer.update([pred[i] for i in idx], [truths[i] for i in idx])
+    return {'cer': cer.compute(), 'wer': wer.compute(), 'chars': cer.total, 'lines': len(idx)}

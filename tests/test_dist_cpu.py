@@ -62,3 +62,21 @@ def test_bucket_edges_are_rank_independent():
     # the padded width of a line (hence its logits: SURVEY 0.6) depends on the line alone
     widths = [417, 640, 903, 1111]
     assert [bucket_width(w) for w in widths] == [bucket_width(w) for w in reversed(widths)][::-1]
+
+
+def test_evaluation_helpers():
+    from conformer_ocr_amd.evaluate import ErrorRate, collate, edit_distance, make_batches
+    assert edit_distance('kitten', 'sitting') == 3 and edit_distance('', 'abc') == 3 and edit_distance('abc', 'abc') == 0
+    cer = ErrorRate()
+    cer.update(['abcd', 'xy'], ['abed', 'xyz'])
+    assert cer.errors == 2 and cer.total == 7 and abs(cer.compute() - 2 / 7) < 1e-12
+    wer = ErrorRate(words=True)
+    wer.update(['the cat sat'], ['the bat sat down'])
+    assert wer.errors == 2 and wer.total == 4
+    widths = [417, 640, 903, 1111, 1200, 1150, 130]
+    b = make_batches(widths, batch_size=2)
+    assert [w for w, _ in b] == [1200, 1200, 1000, 800, 600, 200]
+    assert b[0][1] == [4, 5] and b[1][1] == [3]          # widest first inside a bucket
+    lines = [np.full((4, w), 0.5, np.float32) for w in (5, 3)]
+    im, lens = collate(lines, [0, 1], 8)
+    assert im.shape == (2, 1, 4, 8) and lens.tolist() == [5, 3] and float(im[1, 0, 0, 3]) == 0.0
