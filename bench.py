@@ -62,6 +62,23 @@ def kernel_table(hp, n, w, dtype):
     }
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (collected offline with
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` on this bench command; tools/summarize_rocprof.py), or None."""
+    import csv
+    import glob
+    names = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12'}
+    if family not in names:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.csv')))
+    if not files:
+        return None
+    for r in csv.DictReader(open(files[-1])):
+        if names[family] in r['kernel']:
+            return int(r['hbm_bytes_per_launch(2*fetch+write)'])
+    return None
+
+
 def cpu_baseline(hp, state, width, sample_lines):
     """The CPU oracle (fp32 restatement of the reference forward + greedy decode) on the host cores."""
     from oracle.conformer_ref import Oracle
@@ -211,7 +228,9 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]['share'])
         d = kernels[dom]
         roof = {'kernel': dom, 'bound': 'hbm' if d['bound'] == 'hbm' else 'mfma', 'achieved': d['achieved'], 'peak': d['peak'],
-                'unit': d['unit'], 'frac': d['frac'], 'traffic': None, 'avg_ms': d['avg_ms'], 'share_of_step': d['share']}
+                'unit': d['unit'], 'frac': d['frac'], 'traffic': pmc_traffic(dom), 'avg_ms': d['avg_ms'], 'share_of_step': d['share'],
+                'algorithmic_per_launch': table[dom][1], 'traffic_source': 'profiles/*_pmc_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                'separate passes, 2*FETCH+WRITE bytes per launch)'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

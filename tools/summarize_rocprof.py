@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories into the small CSVs kept under profiles/.
+
+    python tools/summarize_rocprof.py stats  <dir with *_kernel_stats.csv>        > profiles/rNN_kernel_stats.csv
+    python tools/summarize_rocprof.py pmc    <FETCH_SIZE dir> <WRITE_SIZE dir>    > profiles/rNN_pmc_traffic.csv
+
+PMC traffic follows MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are collected in separate passes and
+are reported in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their bytes, so read bytes = 2 x FETCH_SIZE;
+WRITE_SIZE is exact for 16-byte-per-lane stores."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(.*', '', name)
+    m = re.match(r'_Z\d+([a-z_0-9]+kernel)', name)
+    return (m.group(1) if m else name.replace('void ', ''))[:48] + ('<' + name.split('I', 1)[1][:60] if name.startswith('_Z') and 'I' in name else '')
+
+
+def stats(d):
+    f = glob.glob(d + '/**/*_kernel_stats.csv', recursive=True)[0]
+    w = csv.writer(sys.stdout)
+    w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'percent', 'min_ns', 'max_ns'])
+    for r in csv.DictReader(open(f)):
+        w.writerow([r['Name'][:160], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+
+
+def pmc(df, dw):
+    def load(d):
+        f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+        return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+    fe, n = load(df)
+    wr, _ = load(dw)
+    w = csv.writer(sys.stdout)
+    w.writerow(['kernel', 'dispatches', 'FETCH_SIZE_KiB_avg', 'WRITE_SIZE_KiB_avg', 'hbm_bytes_per_launch(2*fetch+write)'])
+    for k in sorted(fe, key=lambda k: -fe[k] * n[k]):
+        w.writerow([k[:160], n[k], round(fe[k], 1), round(wr.get(k, 0.0), 1), int((2 * fe[k] + wr.get(k, 0.0)) * 1024)])
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2], sys.argv[3])
