@@ -107,21 +107,41 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     };
     load_tile(0);
 
-    // B operands: (q + u) and (q + v) of this lane's query, per k-chunk; padded dims stay zero
+    // B operands: (q + u) and (q + v) of this lane's query, per k-chunk; padded dims stay zero.  All loads (q fragments
+    // and the 8 consecutive bias values of each) are issued before the first use: one round trip, not one per element.
     frag_t qu[KC], qv[KC];
     {
         const T *qrow = q + ((size_t)bh * Tp + iq) * DHP;
+        frag_t qq[KC];
+        f32x4 u4[KC][2], v4[KC][2];
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
-            const frag_t qq = load_frag(qrow + c * 32 + 8 * g);
+            qq[c] = load_frag(qrow + c * 32 + 8 * g);
+            const int d0 = min(c * 32 + 8 * g, max(dh - 8, 0));     // clamped: values beyond dh are masked below
+            if ((dh & 7) == 0) {
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    u4[c][hlf] = *reinterpret_cast<const f32x4 *>(ub + hh * dh + d0 + 4 * hlf);
+                    v4[c][hlf] = *reinterpret_cast<const f32x4 *>(vb + hh * dh + d0 + 4 * hlf);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int d = min(c * 32 + 8 * g + j, dh - 1);
+                    u4[c][j >> 2][j & 3] = ub[hh * dh + d];
+                    v4[c][j >> 2][j & 3] = vb[hh * dh + d];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = c * 32 + 8 * g + j;
-                const float x = to_f32(qq[j]);
-                qu[c][j] = d < dh ? from_f32<T>(x + ub[hh * dh + d]) : (T)0.0f;
-                qv[c][j] = d < dh ? from_f32<T>(x + vb[hh * dh + d]) : (T)0.0f;
+                const float x = to_f32(qq[c][j]);
+                qu[c][j] = d < dh ? from_f32<T>(x + u4[c][j >> 2][j & 3]) : (T)0.0f;
+                qv[c][j] = d < dh ? from_f32<T>(x + v4[c][j >> 2][j & 3]) : (T)0.0f;
             }
-        }
     }
 
     f32x4 o[DT];

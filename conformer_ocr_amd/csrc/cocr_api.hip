@@ -627,8 +627,8 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     T *za = (T *)m->z_a, *zb = (T *)m->z_b;
     {
         ProfScope ps(m, s, FAM_CONV12);
-        const int TB = std::max(1, 256 / C);
-        const size_t lds = (size_t)(4 * TB + 3) * (H + 8) * 4;
+        const int TB = std::max(1, 512 / C);                 // 256 threads = TB time steps x C/2 channel pairs
+        const size_t lds = (size_t)(4 * TB + 3) * ((H + 11) & ~3) * 4;
         hipLaunchKernelGGL((frontend_conv12_kernel<T, TIn>), dim3(ceil_div(T2, TB), N), dim3(256), lds, s, lines, H, W, T1, F1, T2, F2, C,
                            F32(P.w0), F32(P.b0), F32(P.stages[0].dw_w), F32(P.stages[0].dw_b), za, TB);
         LAUNCH_CHECK();

@@ -17,7 +17,11 @@
 //
 // Work split: a workgroup takes TB consecutive t of one line; its 256 threads are (t_local, channel)
 // pairs.  The 4*TB+3 image columns the group needs are staged once in LDS as fp32 (transposed,
-// [column][row+4], zero borders), every thread walks f = 0..F-1 keeping the previous Z1 column.
+// [column][row+1], zero borders), every thread walks f = 0..F-1 keeping the previous Z1 column.
+template <typename T> struct Pair;
+template <> struct Pair<bf16_t> { typedef bf16x2 type; };
+template <> struct Pair<float> { typedef f32x2 type; };
+
 template <typename TIn> __device__ __forceinline__ float pixel_to_f32(TIn v);
 template <> __device__ __forceinline__ float pixel_to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float pixel_to_f32<uint8_t>(uint8_t v) { return (float)v / 255.0f; }
@@ -27,48 +31,66 @@ __global__ __launch_bounds__(256) void frontend_conv12_kernel(const TIn *__restr
                                                               const float *__restrict__ w0, const float *__restrict__ b0,
                                                               const float *__restrict__ w2, const float *__restrict__ b2,
                                                               T *__restrict__ Z2, int TB) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [ncols][H + 8]
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [ncols][HS]: LDS row rr <-> image row rr - 1, zero borders
     const int b = blockIdx.y, t0 = blockIdx.x * TB;
-    const int ncols = 4 * TB + 3, HS = H + 8;
+    const int ncols = 4 * TB + 3, HS = (H + 11) & ~3;            // rows -1 .. H+6 at least, multiple of 4 (16-byte row groups)
     const int col0 = 4 * t0 - 3;
     const TIn *Xb = X + (size_t)b * H * W;
     for (int i = threadIdx.x; i < ncols * HS; i += blockDim.x) {
-        const int ci = i / HS, rr = i - ci * HS;     // LDS row rr <-> image row rr - 4
-        const int w = col0 + ci, r = rr - 4;
-        xs[i] = (w >= 0 && w < W && r >= 0 && r < H) ? pixel_to_f32<TIn>(Xb[(size_t)r * W + w]) : 0.0f;
+        const int ci = i / HS, rr = i - ci * HS;
+        const int w = min(max(col0 + ci, 0), W - 1), r = min(max(rr - 1, 0), H - 1);      // clamped address + select: no branch around the load
+        const float v = pixel_to_f32<TIn>(Xb[(size_t)r * W + w]);
+        xs[i] = (col0 + ci >= 0 && col0 + ci < W && rr >= 1 && rr <= H) ? v : 0.0f;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < TB * C; idx += blockDim.x) {
-        const int tl = idx / C, c = idx - tl * C;
+    // Each thread owns TWO adjacent channels of one t: every multiply-add is a packed v_pk_fma_f32 (the kernel is VALU-issue
+    // bound: 63 fused multiply-adds per output and channel), the pixel operand is shared by both halves.  C is even.
+    const int C2 = C >> 1;
+    for (int idx = threadIdx.x; idx < TB * C2; idx += blockDim.x) {
+        const int tl = idx / C2, c = 2 * (idx - tl * C2);
         const int t = t0 + tl;
         if (t >= Tn) continue;
-        float k0[9], k2[9];
+        f32x2 k0[9], k2[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { k0[i] = w0[c * 9 + i]; k2[i] = w2[c * 9 + i]; }
-        const float bias0 = b0[c], bias2 = b2[c];
-        // Z1 column at (t1 = 2t-1+a, f1): image columns 2 t1 + dt - 1 = col0 + 4 tl + 2a + dt
-        const float *xc = xs + (4 * tl) * HS + 4;     // xc[(2a+dt)*HS + r] = X[r][4t-3+2a+dt]
-        auto z1 = [&](int a, int f1) -> float {
-            const int t1 = 2 * t - 1 + a;
-            if (t1 < 0 || t1 >= T1 || f1 < 0 || f1 >= F1) return 0.0f;   // zero padding of the second conv
-            float s = bias0;
+        for (int i = 0; i < 9; ++i) { k0[i] = (f32x2){w0[c * 9 + i], w0[(c + 1) * 9 + i]}; k2[i] = (f32x2){w2[c * 9 + i], w2[(c + 1) * 9 + i]}; }
+        const f32x2 bias0 = {b0[c], b0[c + 1]}, bias2 = {b2[c], b2[c + 1]};
+        // Image rows 4f-1 .. 4f+2 of the 7 columns this (t, .) needs are one aligned 16-byte LDS group per column (row group f);
+        // output f uses row groups f and f+1: one ds_read_b128 per column per f (wave-uniform address: a broadcast read).
+        const float *xc = xs + (4 * tl) * HS;                // column ci of this t: xc + ci * HS
+        f32x4 cur[7], nxt[7];
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-                for (int df = 0; df < 3; ++df) s += k0[dt * 3 + df] * xc[(2 * a + dt) * HS + 2 * f1 + df - 1];
-            return fmaxf(s, 0.0f);
-        };
-        float prev[3] = {0.f, 0.f, 0.f};              // Z1[.][f1 = 2f - 1], f = 0: outside
+        for (int ci = 0; ci < 7; ++ci) cur[ci] = *reinterpret_cast<const f32x4 *>(xc + ci * HS);
+        // validity of the three Z1 columns (t1 = 2t-1+a) is per thread, of the Z1 rows (f1) per step
+        const bool tv[3] = {2 * t - 1 >= 0 && 2 * t - 1 < T1, 2 * t < T1, 2 * t + 1 < T1};
+        const f32x2 zero2 = {0.f, 0.f};
+        f32x2 prev[3] = {zero2, zero2, zero2};                // Z1[.][f1 = 2f - 1], f = 0: outside
+        typedef typename Pair<T>::type P2;
         T *out = Z2 + (((size_t)b * Tn + t) * F) * C + c;
         for (int f = 0; f < F; ++f) {
-            float s = bias2;
+#pragma unroll
+            for (int ci = 0; ci < 7; ++ci) nxt[ci] = *reinterpret_cast<const f32x4 *>(xc + ci * HS + 4 * (f + 1));
+            f32x2 s = bias2;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float m = z1(a, 2 * f), n = z1(a, 2 * f + 1);
+                // Z1(a, 2f): image rows 4f-1+df = element df of the current group; Z1(a, 2f+1): rows 4f+1+df = elements 2, 3 and next[0]
+                f32x2 m = bias0, n = bias0;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    const f32x4 x0 = cur[2 * a + dt];
+                    const float x4 = nxt[2 * a + dt][0];
+                    m += k0[dt * 3 + 0] * (f32x2){x0[0], x0[0]} + k0[dt * 3 + 1] * (f32x2){x0[1], x0[1]} + k0[dt * 3 + 2] * (f32x2){x0[2], x0[2]};
+                    n += k0[dt * 3 + 0] * (f32x2){x0[2], x0[2]} + k0[dt * 3 + 1] * (f32x2){x0[3], x0[3]} + k0[dt * 3 + 2] * (f32x2){x4, x4};
+                }
+                const bool vm = tv[a] && 2 * f < F1, vn = tv[a] && 2 * f + 1 < F1;          // zero padding of the second conv outside Z1
+                m = vm ? (f32x2){fmaxf(m[0], 0.0f), fmaxf(m[1], 0.0f)} : zero2;
+                n = vn ? (f32x2){fmaxf(n[0], 0.0f), fmaxf(n[1], 0.0f)} : zero2;
                 s += k2[a * 3 + 0] * prev[a] + k2[a * 3 + 1] * m + k2[a * 3 + 2] * n;
                 prev[a] = n;
             }
-            out[(size_t)f * C] = from_f32<T>(s);
+            P2 o; o[0] = from_f32<T>(s[0]); o[1] = from_f32<T>(s[1]);
+            *reinterpret_cast<P2 *>(out + (size_t)f * C) = o;
+#pragma unroll
+            for (int ci = 0; ci < 7; ++ci) cur[ci] = nxt[ci];
         }
     }
 }
@@ -103,9 +125,6 @@ __global__ __launch_bounds__(256) void dw3x3s2_kernel(const T *__restrict__ in, 
 // Workgroup = TT output frames x 256 channels of one line; the TT+k-1 input frames are staged in LDS
 // (coalesced over channels); each of 128 threads owns two adjacent channels.  HBM-bound: algorithmic
 // bytes = one read + one write of the (B,T,D) operand.
-template <typename T> struct Pair;
-template <> struct Pair<bf16_t> { typedef bf16x2 type; };
-template <> struct Pair<float> { typedef f32x2 type; };
 
 template <typename T, int TT>
 __global__ __launch_bounds__(128) void dwconv_bn_silu_kernel(const T *__restrict__ g, int Tn, int D, int k,
