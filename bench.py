@@ -102,7 +102,7 @@ def cpu_baseline(hp, state, width, sample_lines):
             greedy_decoder(logits[n, :int(ol[n])].numpy().T)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 8.0 or reps >= 3:
+        if dt > 12.0 or reps >= 8:
             break
     return {'value': round(sample_lines * reps / dt, 3), 'unit': 'lines/s', 'cores': cores, 'kind': 'port',
             'sample': f'{reps} x {sample_lines} lines of 96x{width}, fp32 torch-CPU oracle forward + greedy decode, {dt:.1f} s'}
@@ -111,8 +111,8 @@ def cpu_baseline(hp, state, width, sample_lines):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--width', type=int, default=1200)
     ap.add_argument('--config', default='cfg2')
@@ -234,7 +234,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(hp, state, args.width, sample_lines=2)
+        cpu = cpu_baseline(hp, state, args.width, sample_lines=args.batch)
 
     if rank == 0:
         gflop = flops_per_line(hp, args.width) / 1e9
