@@ -126,7 +126,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    use_dist = 'RANK' in os.environ          # launched by torch.distributed.run (any world size, also 1)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -149,7 +150,7 @@ def main():
     else:
         for e in engines:
             e.finalize_empty()
-    if world > 1:
+    if use_dist:
         from conformer_ocr_amd.dist import broadcast_weights
         for e in engines:
             broadcast_weights(e, src=0)
@@ -187,7 +188,7 @@ def main():
         return eng.ctc_greedy(logits, out_lens)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -197,7 +198,7 @@ def main():
     recs = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -251,7 +252,7 @@ def main():
             'labels_emitted_last_step': int(sum(len(r) for r in recs)),
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

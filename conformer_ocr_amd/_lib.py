@@ -34,6 +34,8 @@ SYMBOLS = {
     'cocr_finalize': (_I, [_P, _I]),
     'cocr_finalize_empty': (_I, [_P, _I]),
     'cocr_weight_blob': (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    'cocr_blob_export': (_I, [_P, _P, C.c_size_t, _P]),
+    'cocr_blob_import': (_I, [_P, _P, C.c_size_t, _P]),
     'cocr_out_len': (C.c_int32, [C.c_int32, C.c_int32]),
     'cocr_reserve': (_I, [_P, _I, _I]),
     'cocr_forward': (_I, [_P, _P, _I, _I, _I, _I, _I32P, _P, _I32P, _P]),

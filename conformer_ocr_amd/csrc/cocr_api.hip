@@ -350,6 +350,25 @@ extern "C" int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes)
     return COCR_OK;
 }
 
+// Copies between the packed blob and a caller-owned device buffer (a collective library's registered / framework-owned
+// memory): rank 0 exports, broadcasts, the other ranks import.  Stream-ordered on `stream`.
+extern "C" int cocr_blob_export(cocr_model *m, void *dst_device, size_t bytes, void *stream) {
+    if (!m || !dst_device) return fail(COCR_EINVAL, "null argument");
+    if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (bytes != m->plan.total) return fail(COCR_EINVAL, "blob is %zu bytes, buffer %zu", m->plan.total, bytes);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(dst_device, m->blob, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return COCR_OK;
+}
+extern "C" int cocr_blob_import(cocr_model *m, const void *src_device, size_t bytes, void *stream) {
+    if (!m || !src_device) return fail(COCR_EINVAL, "null argument");
+    if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (bytes != m->plan.total) return fail(COCR_EINVAL, "blob is %zu bytes, buffer %zu", m->plan.total, bytes);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(m->blob, src_device, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return COCR_OK;
+}
+
 extern "C" int cocr_finalize(cocr_model *m, int dtype) {
     if (!m) return fail(COCR_EINVAL, "null argument");
     if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");

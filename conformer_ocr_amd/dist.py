@@ -14,9 +14,14 @@ import torch.distributed as dist
 
 
 def broadcast_weights(engine, src: int = 0, group=None) -> None:
-    """Rank `src` ran `finalize()`, the others `finalize_empty()`: one in-place broadcast of the device blob."""
-    blob = engine.weight_blob()
-    dist.broadcast(blob, src=src, group=group)
+    """Rank `src` ran `finalize()`, the others `finalize_empty()`: ONE broadcast of the packed device blob
+    (RCCL over xGMI with the "nccl" backend), through a torch-owned staging buffer (`cocr_blob_export` / `_import`)."""
+    buf = torch.empty(engine.blob_nbytes(), dtype=torch.uint8, device=engine.device)
+    if dist.get_rank(group) == src:
+        engine.export_blob(buf)
+    dist.broadcast(buf, src=src, group=group)
+    if dist.get_rank(group) != src:
+        engine.import_blob(buf)
     torch.cuda.synchronize(engine.device)
 
 

@@ -88,6 +88,25 @@ class HipRecognizer:
                 s.__cuda_array_interface__ = {'shape': (n.value,), 'typestr': '|u1', 'data': (p.value, False), 'version': 2}
         return torch.as_tensor(_Mem(self), device=self.device)
 
+    def blob_nbytes(self) -> int:
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self.lib.cocr_weight_blob(self._h, C.byref(p), C.byref(n)))
+        return int(n.value)
+
+    def export_blob(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Packed weights copied into a torch-owned uint8 tensor (the buffer a collective runs on)."""
+        n = self.blob_nbytes()
+        buf = out if out is not None else torch.empty(n, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_blob_export(self._h, C.c_void_p(buf.data_ptr()), n, _stream_ptr(self.device)))
+        return buf
+
+    def import_blob(self, buf: torch.Tensor) -> None:
+        if buf.dtype != torch.uint8 or buf.device != self.device or not buf.is_contiguous():
+            raise ValueError('blob buffer must be a contiguous uint8 tensor on the model device')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_blob_import(self._h, C.c_void_p(buf.data_ptr()), buf.numel(), _stream_ptr(self.device)))
+
     # ---- compute -------------------------------------------------------------------------------
     def out_len(self, w: int) -> int:
         return int(self.lib.cocr_out_len(int(w), self.hp.subsampling_factor))

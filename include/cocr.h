@@ -85,6 +85,10 @@ int cocr_finalize(cocr_model *m, int compute_dtype);
  * that ran cocr_finalize), and is then ready.  The blob layout depends only on (hparams, dtype). */
 int cocr_finalize_empty(cocr_model *m, int compute_dtype);
 int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes);
+/* The same through a caller-owned device buffer of exactly `bytes` = blob size (stream-ordered device-to-device copies):
+ * export on the root, broadcast the caller's buffer, import on the other ranks. */
+int cocr_blob_export(cocr_model *m, void *dst_device, size_t bytes, void *stream);
+int cocr_blob_import(cocr_model *m, const void *src_device, size_t bytes, void *stream);
 
 /* calc_length (convolution.py:240-247) with k=3, s=2, p=1 repeated log2(subsampling_factor) times. */
 int32_t cocr_out_len(int32_t in_len, int32_t subsampling_factor);

@@ -112,3 +112,22 @@ def test_padding_leak_is_kept(case):
     hp, state, image, lens, g = case('tiny')
     _, alone, _ = run_hip(hp, state, image[1:2, :, :, :40].copy(), np.array([37]), 'fp32')
     assert np.abs(alone[0] - g['logits'][1, :alone.shape[1]]).max() > 1e-3
+
+
+def test_weight_blob_export_import_roundtrip(case):
+    """The multi-GPU start-up path on one GPU: a model that never saw the state dict, filled from another model's packed blob
+    (what the RCCL broadcast delivers), produces bit-identical logits."""
+    from tests.hip_util import make_engine
+    from conformer_ocr_amd.engine import HipRecognizer
+    hp, state, image, lens, g = case('tiny')
+    a = make_engine(hp, state, 'bf16')
+    b = HipRecognizer(hp, torch.device('cuda', 0), 'bf16')
+    b.finalize_empty()
+    assert b.blob_nbytes() == a.blob_nbytes() > 0
+    b.import_blob(a.export_blob())
+    x = torch.from_numpy(image[:, 0]).cuda()
+    la, _ = a.forward(x, lens)
+    lb, _ = b.forward(x, lens)
+    assert torch.equal(la, lb)
+    view = a.weight_blob()                       # zero-copy view of the library-owned blob
+    assert view.dtype == torch.uint8 and view.numel() == a.blob_nbytes() and torch.equal(view, a.export_blob())
