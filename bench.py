@@ -122,6 +122,10 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a captured hipGraph')
     ap.add_argument('--streams', type=int, default=3, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
+    # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL at communicator creation) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -251,7 +255,7 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
             'labels_emitted_last_step': int(sum(len(r) for r in recs)),
         }
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
