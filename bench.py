@@ -51,6 +51,10 @@ def kernel_table(hp, n, w, dtype):
         'gemm_ffn_up': ('mfma', 2.0 * M * D * ff),
         'gemm_ffn_down': ('mfma', 2.0 * M * D * ff),
         'ffn_fused': ('mfma', 4.0 * M * D * ff),
+        'chain_ffn_qkv': ('mfma', 4.0 * M * D * ff + 6.0 * M * D * D),
+        'chain_attn_out_glu': ('mfma', 6.0 * M * D * D),
+        'chain_pw2_ffn_ffn_qkv': ('mfma', 8.0 * M * D * ff + 8.0 * M * D * D),
+        'chain_pw2_ffn': ('mfma', 4.0 * M * D * ff + 2.0 * M * D * D),
         'gemm_qkv': ('mfma', 2.0 * M * D * 3 * D),
         'attention': ('mfma', 2.0 * n * 3 * T * T * D),
         'gemm_attn_out': ('mfma', 2.0 * M * D * D),

@@ -23,6 +23,7 @@
 #include "ctc.hip.h"
 #include "gemm.hip.h"
 #include "ffn.hip.h"
+#include "chain.hip.h"
 #include "norm.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
@@ -104,6 +105,7 @@ struct cocr_model {
     struct GraphEntry { const void *lines; float *logits; int N, W, dtype; hipStream_t s; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs, graph_seen;
     bool debug = false;
+    bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
     bool profile = false;
@@ -112,9 +114,9 @@ struct cocr_model {
 };
 
 static const char *FAMILIES[] = {"frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
-                                 "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
+                                 "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "chain_ffn_qkv", "chain_attn_out_glu", "chain_pw2_ffn_ffn_qkv", "chain_pw2_ffn", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
                                  "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam"};
-enum { FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
+enum { FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_CH_FIRST, FAM_CH_A, FAM_CH_B, FAM_CH_LAST, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
        FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_COUNT };
 
 static int out_len1(int l) { return l >= 1 ? (l - 1) / 2 + 1 : 0; }
@@ -152,6 +154,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     m->ff = hp->feed_forward_expansion_factor * hp->encoder_dim; m->ksz = hp->conv_kernel_size;
     m->ncls = hp->num_classes; m->H = hp->height; m->snum = snum;
     { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_NO_CHAIN"); m->no_chain = e && e[0] == '1'; }
     int f = hp->height;
     for (int i = 0; i < snum; ++i) { f = out_len1(f); m->feats.push_back(f); }
     // expected state-dict entries, reference key names
@@ -733,6 +736,74 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         m->vtN = N; m->vtT = Tn;
     }
     char nm[64];
+    if constexpr (sizeof(T) == 2) {
+        if (rowln && chain_supported(D, ff, dh) && !m->debug && !m->no_chain) {
+            // ---- row-local chains (chain.hip.h): 4 launches per block
+            auto base = [&]() { ChainArgs a{}; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
+            auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
+                ChainStage st{}; st.kind = ST_ROWLN; st.W = (const bf16_t *)WT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha; st.has_resid = 1;
+                st.g1 = F32(g1); st.b1 = F32(b1); return st; };
+            auto st_ffn = [&](const FfnW &fw, size_t g1, size_t b1, long g2, long b2) {
+                ChainStage st{}; st.kind = ST_FFN; st.W = (const bf16_t *)WT(fw.w1); st.W2 = (const bf16_t *)WT(fw.w2); st.bias = F32(fw.b1); st.bias2 = F32(fw.b2);
+                st.N = ff; st.alpha = ffr; st.has_resid = 1; st.g1 = F32(g1); st.b1 = F32(b1);
+                st.g2 = g2 >= 0 ? F32((size_t)g2) : nullptr; st.b2 = b2 >= 0 ? F32((size_t)b2) : nullptr; return st; };
+            auto st_qkv = [&](const LayerW &lw) {
+                ChainStage st{}; st.kind = ST_QKV; st.W = (const bf16_t *)WT(lw.wqkv); st.bias = F32(lw.bqkv); st.N = 3 * D;
+                st.q = (bf16_t *)q; st.k = (bf16_t *)k; st.v = (bf16_t *)v; return st; };
+            {   // first block's FFN + q/k/v projection on the frontend output
+                ChainArgs a = base(); a.A0 = (const bf16_t *)xn; a.nstages = 2;
+                a.st[0] = st_ffn(P.layers[0].ffn[0], P.layers[0].a_ln_g, P.layers[0].a_ln_b, -1, -1); a.st[0].store_x = 1;
+                a.st[1] = st_qkv(P.layers[0]);
+                ProfScope ps(m, s, FAM_CH_FIRST);
+                GEMM_TRY(launch_chain(s, a, ff));
+            }
+            for (int l = 0; l < m->L; ++l) {
+                const LayerW &w = P.layers[l];
+                {
+                    ProfScope ps(m, s, FAM_ATTN);
+                    dim3 grid(ceil_div(Tn, 64), N * heads);
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
+                    if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
+#undef ATTN
+                }
+                {   // out-proj + residual + conv-module LayerNorm -> pointwise conv 1 + GLU
+                    ChainArgs a = base(); a.A0 = (const bf16_t *)ctx; a.nstages = 2;
+                    a.st[0] = st_rowln(w.wo, w.bo, 1.0f, w.c_ln_g, w.c_ln_b); a.st[0].store_x = 1;
+                    ChainStage g{}; g.kind = ST_GLU; g.W = (const bf16_t *)WT(w.wpw1); g.bias = F32(w.bpw1); g.N = 2 * D; g.out = (bf16_t *)glu;
+                    a.st[1] = g;
+                    ProfScope ps(m, s, FAM_CH_A);
+                    GEMM_TRY(launch_chain(s, a, ff));
+                }
+                {
+                    ProfScope ps(m, s, FAM_DW);
+                    launch_dwconv<T>(s, glu, N, Tn, D, m->ksz, F32(w.dww), F32(w.dwb), dwo);
+                    LAUNCH_CHECK();
+                }
+                {   // pointwise conv 2 + residual + LayerNorm -> FFN 2 (+ closing LayerNorm [+ next block's]) [-> next block's FFN 1 -> its q/k/v]
+                    ChainArgs a = base(); a.A0 = (const bf16_t *)dwo;
+                    a.st[0] = st_rowln(w.wpw2, w.bpw2, 1.0f, w.ffn[1].ln_g, w.ffn[1].ln_b);
+                    if (l + 1 < m->L) {
+                        const LayerW &nx = P.layers[l + 1];
+                        a.st[1] = st_ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, (long)nx.ffn[0].ln_g, (long)nx.ffn[0].ln_b);
+                        a.st[2] = st_ffn(nx.ffn[0], nx.a_ln_g, nx.a_ln_b, -1, -1); a.st[2].store_x = 1;
+                        a.st[3] = st_qkv(nx);
+                        a.nstages = 4;
+                        ProfScope ps(m, s, FAM_CH_B);
+                        GEMM_TRY(launch_chain(s, a, ff));
+                    } else {
+                        a.st[1] = st_ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, -1, -1); a.st[1].store_x = 1; a.st[1].store_xn = 1;
+                        a.nstages = 2;
+                        ProfScope ps(m, s, FAM_CH_LAST);
+                        GEMM_TRY(launch_chain(s, a, ff));
+                    }
+                }
+            }
+            ProfScope ps(m, s, FAM_DEC);
+            EpiStoreF32 e{logits, m->ncls, F32(P.bdec), m->ncls};
+            GEMM_TRY(launch_gemm<T>(s, xn, D, WT(P.wdec), D, M, m->ncls, D, e));
+            return COCR_OK;
+        }
+    }
     for (int l = 0; l < m->L; ++l) {
         const LayerW &w = P.layers[l];
         // FFN, half-step residual (feed_forward.py:45-52, encoder.py:68-75); epilogue: LayerNorm of the attention module

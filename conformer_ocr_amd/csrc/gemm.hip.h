@@ -206,6 +206,66 @@ template <typename T, int NV> struct EpiResidualLN {
     __device__ __forceinline__ void rows4(int m0, int M, const float *staged, int rs_floats, int lane) const {
         rows4(m0, M, staged, rs_floats, lane, rows4_load(m0, M, lane));
     }
+    // Chain form (chain.hip.h): the residual rows come in through `xr` and the NEW stream rows go back out through it (the next
+    // stage of the chain adds to them without touching global memory); x / xn are written to global only when asked; the new
+    // normalised rows are also written as bf16 into the swizzled operand image `lds` (panels of [rows][128 B], tile row = row0 + r).
+    __device__ __forceinline__ void rows4_chain(int m0, int M, const float *staged, int rs_floats, int lane, Rows4 &xr, int store_x, int store_xn,
+                                                unsigned char *lds, int row0, int panel_bytes) const {
+        static_assert(NV == 1, "chain kernels are written for encoder_dim <= 256");
+        const int nchunk = D >> 2;
+        const float inv_d = 1.0f / (float)D;
+        const int c = lane, cc = min(c, nchunk - 1);
+        f32x4 xv[4];
+        float s[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 t = *reinterpret_cast<const f32x4 *>(staged + r * rs_floats + 4 * cc);
+            if (has_resid) t += xr.v[r][0];
+            if (c >= nchunk) t = (f32x4){0, 0, 0, 0};
+            xv[r] = t;
+            s[r] = t[0] + t[1] + t[2] + t[3];
+        }
+        auto normalise = [&](const float *gam, const float *bet) {
+            float mean[4], q[4], rstd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mean[r] = wave_sum(s[r]) * inv_d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                q[r] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = c < nchunk ? xv[r][e] - mean[r] : 0.f; q[r] += d * d; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(q[r]) * inv_d + 1e-5f);
+            const f32x4 ga = c < nchunk ? *reinterpret_cast<const f32x4 *>(gam + 4 * cc) : (f32x4){0, 0, 0, 0};
+            const f32x4 be = c < nchunk ? *reinterpret_cast<const f32x4 *>(bet + 4 * cc) : (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[r][e] = (xv[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
+                s[r] = xv[r][0] + xv[r][1] + xv[r][2] + xv[r][3];
+            }
+        };
+        auto keep_x = [&]() {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xr.v[r][0] = xv[r];
+                if (store_x && m0 + r < M && c < nchunk) *reinterpret_cast<f32x4 *>(x + (size_t)(m0 + r) * D + 4 * c) = xv[r];
+            }
+        };
+        if (!g2) keep_x();
+        normalise(g1, b1);
+        if (g2) { keep_x(); normalise(g2, b2); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bf16x4 o = {(T)xv[r][0], (T)xv[r][1], (T)xv[r][2], (T)xv[r][3]};
+            if (c < nchunk) {
+                const int row = row0 + r, col = 4 * c;
+                *reinterpret_cast<bf16x4 *>(lds + (col >> 6) * panel_bytes + row * 128 + ((((col & 63) >> 3) ^ (row & 7)) << 4) + ((col & 7) >> 2) * 8) = o;
+                if (store_xn && m0 + r < M) *reinterpret_cast<bf16x4 *>(xn + (size_t)(m0 + r) * D + col) = o;
+            }
+        }
+    }
     // rows m0 .. m0+3 (row r valid if m0 + r < M); staged row r at `staged + r * rs_floats`; xr = rows4_load(m0, M, lane)
     __device__ __forceinline__ void rows4(int m0, int M, const float *staged, int rs_floats, int lane, const Rows4 &xr) const {
         const int nchunk = D >> 2;
