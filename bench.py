@@ -71,7 +71,9 @@ def pmc_traffic(family):
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` on this bench command; tools/summarize_rocprof.py), or None."""
     import csv
     import glob
-    names = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12'}
+    names = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12',
+             'chain_pw2_ffn_ffn_qkv': 'chain_kernel<0, 1, 1, 3>', 'chain_attn_out_glu': 'chain_kernel<0, 2, -1, -1>',
+             'chain_ffn_qkv': 'chain_kernel<1, 3, -1, -1>', 'chain_pw2_ffn': 'chain_kernel<0, 1, -1, -1>'}
     if family not in names:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.csv')))

@@ -10,6 +10,7 @@ WRITE_SIZE is exact for 16-byte-per-lane stores."""
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
@@ -21,7 +22,7 @@ def short(name):
 
 
 def stats(d):
-    f = glob.glob(d + '/**/*_kernel_stats.csv', recursive=True)[0]
+    f = max(glob.glob(d + '/**/*_kernel_stats.csv', recursive=True), key=os.path.getmtime)     # newest run in the directory
     w = csv.writer(sys.stdout)
     w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'percent', 'min_ns', 'max_ns'])
     for r in csv.DictReader(open(f)):
@@ -30,7 +31,7 @@ def stats(d):
 
 def pmc(df, dw):
     def load(d):
-        f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
+        f = max(glob.glob(d + '/**/*_counter_collection.csv', recursive=True), key=os.path.getmtime)
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             agg[r['Kernel_Name']].append(float(r['Counter_Value']))
