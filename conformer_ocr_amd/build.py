@@ -39,6 +39,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-fgpu-rdc' if False else '-fno-gpu-rdc',
            '-Wall', '-Wno-unused-function', '-I', INCLUDE, os.path.join(CSRC, 'cocr_api.hip'), '-o', LIB + '.tmp']
+    cmd[1:1] = os.environ.get('COCR_HIPCC_FLAGS', '').split()      # dev builds, e.g. -DCOCR_CHAIN_STAMPS_BUILD
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

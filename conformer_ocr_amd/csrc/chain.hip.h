@@ -45,6 +45,7 @@ struct ChainArgs {
     float *x;              // fp32 residual stream (M, 256)
     bf16_t *xn;            // normalised operand (M, 256), written when a stage asks for it
     int M, nstages;
+    unsigned long long *stamps;   // dev: cycle stamps of workgroup 0 / wave 0 (COCR_CHAIN_STAMPS), else null
     int dh, dhp, heads, T_, Tp;       // attention layout of the QKV stage
     ChainStage st[4];
 };
@@ -312,5 +313,398 @@ static inline hipError_t launch_chain(hipStream_t s, const ChainArgs &a, int max
     if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_chain_cfg<ST_ROWLN, ST_GLU, -1, -1>(s, a, max_ff);
     if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain_cfg<ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a, max_ff);
     if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain_cfg<ST_ROWLN, ST_FFN, -1, -1>(s, a, max_ff);
+    return hipErrorInvalidValue;
+}
+
+
+// =====================================================================================================================
+// 96-row form: weights stream L2 -> REGISTERS, activations stay in LDS.
+//
+// A CU takes in ~70 GB/s from L2 whatever the instruction (MI355X_MICROARCH.md, "Indexed rows"); a 48-row workgroup streams
+// every weight byte of the chain for 48 rows = 48 flop per ingested byte, a third of what the CU's MFMA rate needs, and the
+// 48-row kernel above is bound by exactly that.  This form doubles the rows per workgroup (the LDS that held the weight
+// slices now holds a 96-row operand image), so the same weight stream feeds twice the arithmetic:
+//   * weights are read from a FRAGMENT-MAJOR copy (pack_frag_kernel: [n/32][k/32][2][64 lanes][8]) so that the 16 MFMA
+//     B-fragments a wave consumes in one step (32 output columns x K = 256) are one contiguous 16 KiB run, each wave
+//     instruction a fully coalesced 1 KiB read straight into the registers the MFMA reads;
+//   * a 16-fragment register ring per wave: fragment (kk, j) of the NEXT step is requested right after the MFMAs that consumed
+//     fragment (kk, j) of this step -- 16 KiB per wave (128 KiB per CU) in flight at all times, across step, stage and
+//     epilogue boundaries; the compiler's vmcnt bookkeeping orders it (no LDS-DMA, no hand-counted waits);
+//   * the operand rows (96 x 256 bf16, 48 KiB swizzled image) and the FFN hidden chunk (96 x 256, double buffered) are MFMA
+//     A-operands read from LDS, 6 row tiles against 2 column tiles per k-step (12 MFMAs per 6 ds_read_b128);
+//   * the fp32 residual rows are re-read from global by the thread that wrote them (L2 hits; same-thread program order),
+//     instead of living in 48 VGPRs.
+// 9600 rows = 100 workgroups: one launch fills 100 CUs, a second stream's launch runs beside it.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t *__restrict__ src, bf16_t *__restrict__ dst, int N, int K) {
+    const size_t units = (size_t)N * K / 8;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+        const int lane = (int)(u & 63), j = (int)((u >> 6) & 1);
+        const size_t blk = u >> 7;                        // (pair, kt)
+        const int kt = (int)(blk % (K / 32)), pair = (int)(blk / (K / 32));
+        const int n = pair * 32 + j * 16 + (lane & 15), k = kt * 32 + 8 * (lane >> 4);
+        *reinterpret_cast<bf16x8 *>(dst + u * 8) = *reinterpret_cast<const bf16x8 *>(src + (size_t)n * K + k);
+    }
+}
+
+// sum over each 16-lane row of the wave (4 DPP steps), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1, 0xF>(v, 0.f);      // quad_perm(1,0,3,2)
+    v += dpp_f32<0x4E, 0xF>(v, 0.f);      // quad_perm(2,3,0,1)
+    v += dpp_f32<0x141, 0xF>(v, 0.f);     // row_half_mirror
+    v += dpp_f32<0x140, 0xF>(v, 0.f);     // row_mirror
+    return v;
+}
+
+template <int K0, int K1, int K2, int K3>
+__global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
+    typedef bf16_t T;
+    constexpr int D = 256, BMC = 96, MT = 6, KC1 = D / 32;
+    constexpr int PANEL = BMC * 128;            // one [96 rows][128 B] panel of an operand image (64 bf16 of k per row)
+    constexpr int IMG = 4 * PANEL;              // 96 x 256 bf16
+    constexpr int RS = D * 4 + 16;              // fp32 staged row (LayerNorm epilogue)
+    constexpr int OS = D * 2 + 16;              // bf16 staged row (GLU / QKV output tiles)
+    constexpr int SLICE = 16 * 512;             // elements in one step's weight run (16 fragments)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *xa = smem;                   // operand image
+    unsigned char *hs = smem + IMG;             // 2 hidden-chunk images; fp32 staging (96 * RS) / 2 output tiles (2 * 96 * OS) alias it (+ 4 KiB slack)
+    const float *lnp = reinterpret_cast<const float *>(smem + 3 * IMG + 4096);   // LayerNorm parameters of the running stage: g1, b1, g2, b2 (4 x 256 floats)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4, swz = r16 & 7;
+    const int M = p.M, m0 = blockIdx.x * BMC, mend = min(M, m0 + BMC);
+    const int lrow = lane >> 3, cpos = lane & 7;
+    auto lds_fence_barrier0 = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- first operand tile -> LDS image: 4 panels x 12 row groups of 8 rows = 48 wave-instructions (6 per wave)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int id = wave + 8 * i, pnl = id / 12, rg = id - pnl * 12, row = rg * 8 + lrow;
+        const T *src = p.A0 + (size_t)min(m0 + row, M - 1) * D + pnl * 64 + ((cpos ^ (row & 7)) * 8);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xa + pnl * PANEL + rg * 1024), 16, 0, 0);
+    }
+    // ---- weight ring: the first step's 16 fragments
+    bf16x8 ring[16];
+    auto fill = [&](const T *slice, int f) { ring[f] = *reinterpret_cast<const bf16x8 *>(slice + f * 512 + lane * 8); };
+    {
+        const T *first = p.st[0].W + (size_t)wave * SLICE;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) fill(first, f);
+    }
+    // row -> offset of its (batch, frame) in the q / k / v layouts [B][h][Tp][dhp] (the q/k/v stage's scatter would otherwise
+    // divide per 16-byte store)
+    long long *rowoff = reinterpret_cast<long long *>(smem + 3 * IMG + 8192);
+    if (tid < BMC) {
+        const int m = min(m0 + tid, M - 1), b = m / p.T_, t = m - b * p.T_;
+        rowoff[tid] = ((long long)b * p.heads * p.Tp + t) * p.dhp;
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // the operand DMAs (older than the 16 ring loads) have landed
+    lds_fence_barrier0();
+
+#ifdef COCR_CHAIN_STAMPS_BUILD                   // dev: cycle stamps of workgroup 0 / thread 0 at the phase boundaries
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (p.stamps && blockIdx.x == 0 && tid == 0) p.stamps[nstamp] = __builtin_readcyclecounter();
+        ++nstamp;
+    };
+#else
+    auto stamp = [&]() {};
+#endif
+    stamp();
+    // One step: acc[96 rows][32 columns of this wave] += image . ring ; ring <- the 16 fragments at `nxt`.  `side(kk)` is
+    // independent VALU work folded into the k-step (the MFMA pipe runs beside it).
+    auto step = [&](const unsigned char *img, f32x4 (&acc)[MT][2], const T *nxt, auto &&side) {
+#pragma unroll
+        for (int kk = 0; kk < KC1; ++kk) {
+            bf16x8 a[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = lds_frag_swz(img + (kk >> 1) * PANEL + (16 * i + r16) * 128, kk & 1, g, swz, T());
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = mma16(ring[2 * kk + j], a[i], acc[i][j]);
+            fill(nxt, 2 * kk);
+            fill(nxt, 2 * kk + 1);
+            side(std::integral_constant<int, 0>{}, kk);
+            __builtin_amdgcn_sched_barrier(0);               // keep the refill (and the side work) here: the scheduler otherwise sinks all of it to the step's end
+        }
+    };
+    auto no_side = [](auto, int) {};
+    auto zero = [&](f32x4 (&acc)[MT][2]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto lds_fence_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // LayerNorm parameters of a stage -> LDS, requested at the stage's start by waves 0..3 (1 KiB each); the epilogue's
+    // vmcnt(16) + barrier publishes them (at least one step = 16 younger ring loads lies between)
+    auto request_ln_params = [&](const ChainStage &st) {
+        if (wave < 4) {
+            const float *src = wave == 0 ? st.g1 : wave == 1 ? st.b1 : wave == 2 ? (st.g2 ? st.g2 : st.g1) : (st.b2 ? st.b2 : st.b1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane * 4), (lds_ptr_t)(smem + 3 * IMG + 4096 + wave * 1024), 16, 0, 0);
+        }
+    };
+    // this wave's 2 x 4 bias values of a 256-column product (requested BEFORE the step: younger loads than the ring's would
+    // make their consumer wait for the whole ring)
+    struct Bias2 { f32x4 v[2]; };
+    auto load_bias = [&](const float *bias) {
+        Bias2 b;
+        b.v[0] = *reinterpret_cast<const f32x4 *>(bias + 32 * wave + 4 * g);
+        b.v[1] = *reinterpret_cast<const f32x4 *>(bias + 32 * wave + 16 + 4 * g);
+        return b;
+    };
+    // alpha (acc + bias) of a 256-column product -> fp32 staging rows
+    auto stage_rows = [&](const f32x4 (&acc)[MT][2], const Bias2 &bb, float alpha) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = 32 * wave + 16 * j + 4 * g;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x4 r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = alpha * (acc[i][j][q] + bb.v[j][q]);
+                *reinterpret_cast<f32x4 *>(hs + (16 * i + r16) * RS + n * 4) = r;
+            }
+        }
+    };
+    // Residual + LayerNorm(s) on the staged tile.  Wave w owns rows 12w .. 12w+11, four at a time: a 16-lane row of the wave
+    // holds one activation row (lane c of it: the float4 chunks c, c+16, c+32, c+48), so the four rows reduce together in
+    // four row-local DPP steps.  x goes back to global (it is this chain's residual storage, re-read by the same thread in
+    // the next epilogue); the normalised rows become the new operand image.
+    //   single:  x <- x + staged ;       xn <- LN1(x)
+    //   chained: x <- LN1(x + staged) ;  xn <- LN2(x)          (block-final LayerNorm + the next block's first)
+    auto rowln_epilogue = [&](const ChainStage &st) {
+        const int rl = lane >> 4, cl = lane & 15;
+        const bool chained = st.g2 != nullptr;
+        // all 12 residual rows requested up front (the accumulators are dead here: registers are free); the x stores below
+        // then never sit in front of a load this epilogue waits for
+        f32x4 xr[3][4];
+        if (st.has_resid) {
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass) {
+                const int m = min(m0 + 12 * wave + 4 * pass + rl, mend - 1);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xr[pass][v] = *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v));
+            }
+        }
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // this stage's LayerNorm parameters have landed
+        lds_fence_barrier();                                 // staged tile complete; every wave is done reading the old image
+        constexpr float inv_d = 1.0f / (float)D;
+        auto normalise = [&](f32x4 (&t)[4], int which) {     // which: 0 = (g1, b1), 1 = (g2, b2)
+            const float *ga = lnp + which * 512, *be = ga + 256;
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) s += (t[v][0] + t[v][1]) + (t[v][2] + t[v][3]);
+            const float mean = row16_sum(s) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[v][e] -= mean; q += t[v][e] * t[v][e]; }
+            const float rstd = __builtin_amdgcn_rsqf(row16_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 gv = *reinterpret_cast<const f32x4 *>(ga + 4 * (cl + 16 * v)), bv = *reinterpret_cast<const f32x4 *>(be + 4 * (cl + 16 * v));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[v][e] = t[v][e] * rstd * gv[e] + bv[e];
+            }
+        };
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            const int row = 12 * wave + 4 * pass + rl;
+            const bool live = m0 + row < mend;
+            f32x4 t[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                t[v] = *reinterpret_cast<const f32x4 *>(hs + row * RS + 16 * (cl + 16 * v));
+                if (st.has_resid) t[v] += xr[pass][v];
+            }
+            float *xrow = p.x + (size_t)(m0 + row) * D;
+            if (!chained) {
+                if (live)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + 4 * (cl + 16 * v)) = t[v];
+                normalise(t, 0);
+            } else {
+                normalise(t, 0);
+                if (live)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + 4 * (cl + 16 * v)) = t[v];
+                normalise(t, 1);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bf16x4 o = {(T)t[v][0], (T)t[v][1], (T)t[v][2], (T)t[v][3]};
+                *reinterpret_cast<bf16x4 *>(xa + v * PANEL + row * 128 + ((((cl >> 1) ^ (row & 7))) << 4) + (cl & 1) * 8) = o;
+                if (st.store_xn && live) *reinterpret_cast<bf16x4 *>(p.xn + (size_t)(m0 + row) * D + 4 * (cl + 16 * v)) = o;
+            }
+        }
+        lds_fence_barrier();                                 // new operand image complete, staging consumed
+    };
+    // cooperative, coalesced copy of a staged bf16 [96][256] tile (row stride OS) to global through `store`
+    auto flush_tile = [&](const unsigned char *tile, int col0, auto &&store) {
+        for (int id = tid; id < BMC * 32; id += 512) {
+            const int row = id >> 5, ch = id & 31;
+            if (m0 + row < mend) store(m0 + row, col0 + ch * 8, reinterpret_cast<const T *>(tile + row * OS + ch * 16));
+        }
+    };
+
+    auto run_stage = [&](auto KIND, const ChainStage &st, const T *after) {      // `after`: this wave's first slice of the next stage
+        constexpr int kind = decltype(KIND)::value;
+        if constexpr (kind == ST_ROWLN) {
+            request_ln_params(st);
+            const Bias2 bb = load_bias(st.bias);
+            f32x4 acc[MT][2];
+            zero(acc);
+            step(xa, acc, after, no_side);
+            stamp();
+            lds_fence_barrier();                             // hs (hidden chunks / output tiles of the previous stage) is free
+            stage_rows(acc, bb, st.alpha);
+            stamp();
+            rowln_epilogue(st);
+            stamp();
+        } else if constexpr (kind == ST_FFN) {
+            // Software pipeline over the 256-wide hidden chunks:   P1(c): hidden(c) = xa W1(c)^T  (MFMA)
+            //                                                      P2(c-1): out += silu(hidden(c-1)) W2(c-1)^T  (MFMA)  beside
+            //                                                      S(c):  bias + SiLU of hidden(c) -> LDS        (VALU, folded into P2(c-1)'s k-steps)
+            // weight stream order: W1(0), W1(1), W2(0), W1(2), W2(1), ..., W2(last).
+            const int FF = st.N, nchunks = FF / 256;
+            auto w1 = [&](int c) { return st.W + (size_t)(c * 8 + wave) * SLICE; };
+            auto w2 = [&](int c) { return st.W2 + ((size_t)wave * (FF / 32) + c * 8) * 1024; };
+            f32x4 acc1[MT][2], acc2[MT][2];
+            Bias2 bb;
+            auto silu_tile = [&](int tIdx, unsigned char *hb) {          // tile t = (row tile t / 2, column tile t % 2) of acc1 -> hb
+                const int i = tIdx >> 1, j = tIdx & 1;
+                const int jj = 32 * wave + 16 * j + 4 * g;               // hidden column inside the chunk
+                const int ch16 = (jj & 63) >> 3, row = 16 * i + r16;
+                bf16x4 hv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = (T)silu_f(acc1[i][j][q] + bb.v[j][q]);
+                *reinterpret_cast<bf16x4 *>(hb + (jj >> 6) * PANEL + row * 128 + ((ch16 ^ (row & 7)) << 4) + ((jj & 7) >> 2) * 8) = hv;
+            };
+            request_ln_params(st);
+            zero(acc2);
+            bb = load_bias(st.bias);
+            zero(acc1);
+            step(xa, acc1, nchunks > 1 ? w1(1) : w2(0), no_side);                      // P1(0)
+            stamp();
+#pragma unroll
+            for (int t2 = 0; t2 < 12; ++t2) silu_tile(t2, hs);                            // S(0)
+            stamp();
+            lds_fence_barrier();
+            stamp();
+            for (int c = 1; c < nchunks; ++c) {
+                bb = load_bias(st.bias + c * 256);
+                zero(acc1);
+                step(xa, acc1, w2(c - 1), no_side);                                       // P1(c)
+                stamp();
+                unsigned char *hb = hs + (c & 1) * IMG;
+                step(hs + ((c - 1) & 1) * IMG, acc2, c + 1 < nchunks ? w1(c + 1) : w2(c),    // P2(c-1) beside S(c)
+                     [&](auto, int kk) {
+                         if (kk < 4) { silu_tile(2 * kk, hb); silu_tile(2 * kk + 1, hb); }
+                         else silu_tile(4 + kk, hb);
+                     });
+                stamp();
+                lds_fence_barrier();
+                stamp();
+            }
+            const Bias2 b2 = load_bias(st.bias2);
+            step(hs + ((nchunks - 1) & 1) * IMG, acc2, after, no_side);                  // P2(last)
+            stamp();
+            lds_fence_barrier();                             // every wave is done reading the hidden chunks
+            stage_rows(acc2, b2, st.alpha);
+            stamp();
+            rowln_epilogue(st);
+            stamp();
+        } else if constexpr (kind == ST_GLU) {
+            // two steps of 256 packed columns: wave w's pair = (value tile, gate tile) of channels step*128 + 16w .. +15
+            EpiGLU<T> e{st.out, D, st.bias, 2 * D};
+            lds_fence_barrier();                             // hs free
+#pragma unroll 1
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Bias2 bb = load_bias(st.bias + s2 * 256);          // v[0]: value bias, v[1]: gate bias
+                f32x4 acc[MT][2];
+                zero(acc);
+                step(xa, acc, s2 == 0 ? st.W + (size_t)(8 + wave) * SLICE : after, no_side);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = 16 * i + r16;
+                    bf16x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = (T)((acc[i][0][q] + bb.v[0][q]) * sigmoid_f(acc[i][1][q] + bb.v[1][q]));
+                    *reinterpret_cast<bf16x4 *>(hs + row * OS + (s2 * 128 + 16 * wave + 4 * g) * 2) = o;
+                }
+            }
+            lds_fence_barrier();
+            flush_tile(hs, 0, [&](int m, int c, const T *src) { e.store(m, c, src, 8); });
+        } else if constexpr (kind == ST_QKV) {   // three steps of 256 columns
+            EpiQKV<T> e{st.q, st.k, st.v, st.bias, D, p.dh, p.dhp, p.heads, p.T_, p.Tp, 3 * D};
+            lds_fence_barrier();                             // hs free
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const Bias2 bb = load_bias(st.bias + s3 * 256);
+                f32x4 acc[MT][2];
+                zero(acc);
+                step(xa, acc, s3 < 2 ? st.W + (size_t)((s3 + 1) * 8 + wave) * SLICE : after, no_side);
+                stamp();
+                unsigned char *tile = hs + (s3 & 1) * (BMC * OS);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int row = 16 * i + r16;
+                        bf16x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = (T)(acc[i][j][q] + bb.v[j][q]);
+                        *reinterpret_cast<bf16x4 *>(tile + row * OS + (32 * wave + 16 * j + 4 * g) * 2) = o;
+                    }
+                lds_fence_barrier();                         // tile s3 complete (tile s3-1 was flushed before this barrier)
+                stamp();
+                {   // step s3 is exactly q, k or v (256 = D columns each); thread -> one 8-column chunk of 6 rows
+                    T *base = s3 == 0 ? st.q : (s3 == 1 ? st.k : st.v);
+                    const int ch = tid & 31, hd = ch * 8, hh = hd / p.dh, d = hd - hh * p.dh;
+                    base += (size_t)hh * p.Tp * p.dhp + d;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const int row = (tid >> 5) + 16 * i;
+                        if (m0 + row < mend) copy16(base + rowoff[row], reinterpret_cast<const T *>(tile + row * OS + ch * 16));
+                    }
+                }
+                stamp();
+            }
+        }
+    };
+    auto first_slice = [&](int i) -> const T * { return p.st[i].W + (size_t)wave * SLICE; };
+    run_stage(std::integral_constant<int, K0>{}, p.st[0], K1 >= 0 ? first_slice(1) : first_slice(0));
+    run_stage(std::integral_constant<int, K1>{}, p.st[1], K2 >= 0 ? first_slice(2) : first_slice(0));
+    run_stage(std::integral_constant<int, K2>{}, p.st[2], K3 >= 0 ? first_slice(3) : first_slice(0));
+    run_stage(std::integral_constant<int, K3>{}, p.st[3], first_slice(0));
+}
+
+template <int K0, int K1, int K2, int K3>
+static inline hipError_t launch_chain96_cfg(hipStream_t s, const ChainArgs &a) {
+    const size_t lds = (size_t)3 * 4 * 96 * 128 + 4096 + 4096 + 1024;      // operand image, 2 hidden images (+ slack), LayerNorm parameters, row offsets
+    auto kern = chain96_kernel<K0, K1, K2, K3>;
+    hipError_t e = raise_lds_limit((const void *)kern, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, 96)), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// the chain shapes the forward uses; stage weights point at the fragment-major copies
+static inline hipError_t launch_chain96(hipStream_t s, const ChainArgs &a) {
+    const int k0 = a.st[0].kind, k1 = a.nstages > 1 ? a.st[1].kind : -1, k2 = a.nstages > 2 ? a.st[2].kind : -1, k3 = a.nstages > 3 ? a.st[3].kind : -1;
+    if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_chain96_cfg<ST_FFN, ST_QKV, -1, -1>(s, a);
+    if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_chain96_cfg<ST_ROWLN, ST_GLU, -1, -1>(s, a);
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a);
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<ST_ROWLN, ST_FFN, -1, -1>(s, a);
     return hipErrorInvalidValue;
 }

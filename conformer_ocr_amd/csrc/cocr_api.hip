@@ -84,6 +84,10 @@ struct cocr_model {
     int dtype = -1;
     unsigned char *blob = nullptr;
     BlobPlan plan;
+    // fragment-major copies of the chain kernels' weight matrices (chain.hip.h), at the blob's offsets; derived from the blob,
+    // rebuilt before the next forward whenever the blob may have changed (finalize, import, cocr_weight_blob handed out)
+    unsigned char *packed = nullptr;
+    bool packed_stale = true;
     // workspace
     int capN = 0, capW = 0;
     std::vector<void *> ws_allocs;
@@ -105,6 +109,8 @@ struct cocr_model {
     struct GraphEntry { const void *lines; float *logits; int N, W, dtype; hipStream_t s; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs, graph_seen;
     bool debug = false;
+    unsigned long long *stamps = nullptr;   // COCR_CHAIN_STAMPS=1 (dev): host-visible cycle stamps of one chain launch, printed at destroy
+    bool chain48 = false;        // COCR_CHAIN48=1: the 48-row LDS-DMA chain kernels instead of the 96-row register-streamed ones (A/B)
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
@@ -155,6 +161,8 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     m->ncls = hp->num_classes; m->H = hp->height; m->snum = snum;
     { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CHAIN"); m->no_chain = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_CHAIN48"); m->chain48 = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_CHAIN_STAMPS"); if (e && e[0] == '1') { (void)hipHostMalloc((void **)&m->stamps, 256 * 8); memset(m->stamps, 0, 256 * 8); } }
     int f = hp->height;
     for (int i = 0; i < snum; ++i) { f = out_len1(f); m->feats.push_back(f); }
     // expected state-dict entries, reference key names
@@ -213,6 +221,14 @@ extern "C" void cocr_destroy(cocr_model *m) {
     free_workspace(m);
     clear_taps(m);
     if (m->blob) (void)hipFree(m->blob);
+    if (m->packed) (void)hipFree(m->packed);
+    if (m->stamps) {
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "chain stamps (cycles since first):");
+        for (int i = 1; i < 256 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[0]);
+        fprintf(stderr, "\n");
+        (void)hipHostFree(m->stamps);
+    }
     if (m->d_lens) (void)hipFree(m->d_lens);
     if (m->ctc_lab) (void)hipFree(m->ctc_lab);
     if (m->ctc_val) (void)hipFree(m->ctc_val);
@@ -330,6 +346,8 @@ static int alloc_blob(cocr_model *m, int dtype) {
     if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");
     HIP_TRY(hipSetDevice(m->device));
     if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
+    if (m->packed) { (void)hipFree(m->packed); m->packed = nullptr; }
+    m->packed_stale = true;
     m->plan = make_plan(m, dtype);
     m->dtype = dtype;
     HIP_TRY(hipMalloc((void **)&m->blob, m->plan.total));
@@ -350,6 +368,7 @@ extern "C" int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes)
     if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
     *device_ptr = m->blob;
     *bytes = m->plan.total;
+    m->packed_stale = true;          // the caller may write through the pointer: derived copies are rebuilt by the next forward
     return COCR_OK;
 }
 
@@ -369,6 +388,7 @@ extern "C" int cocr_blob_import(cocr_model *m, const void *src_device, size_t by
     if (bytes != m->plan.total) return fail(COCR_EINVAL, "blob is %zu bytes, buffer %zu", m->plan.total, bytes);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(m->blob, src_device, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    m->packed_stale = true;
     return COCR_OK;
 }
 
@@ -725,8 +745,25 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         { ProfScope ps(m, s, FAM_FFN_UP); EpiBiasAct<T, ACT_SILU> e{hid, ff, F32(fw.b1), ff}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(fw.w1), D, M, ff, D, e)); }
         return gemm_to_stream(FAM_FFN_DOWN, hid, ff, fw.w2, fw.b2, ffr, true, g1, b1, g2, b2);
     };
-    // flatten (b,t,(f,c)) is a view of the channel-last tensor; the output linear writes the fp32 residual stream
-    if ((rc = gemm_to_stream(FAM_FOUT, zcur, F * C, P.wout, P.bout, 1.0f, false, P.layers[0].ffn[0].ln_g, P.layers[0].ffn[0].ln_b, -1, -1))) return rc;
+    // flatten (b,t,(f,c)) is a view of the channel-last tensor; the output linear writes the fp32 residual stream.
+    // K = F*C (6144) against N = D: split-K over 4 workgroup groups (partials in the idle frontend buffer), then one pass
+    // sums them, adds the bias and applies the first block's LayerNorm.
+    {
+        constexpr int SPLITS = 4;
+        const int Kf = F * C;
+        const bool splitk = rowln && !m->debug && (Kf % (SPLITS * (128 / (int)sizeof(T))) == 0) && D <= 256 &&
+                            (size_t)SPLITS * M * D * 4 <= (size_t)N * T2 * F2 * C * sizeof(T);
+        if (splitk) {
+            float *partial = reinterpret_cast<float *>(zcur == zb ? za : zb);          // the other frontend buffer is free now
+            { ProfScope ps(m, s, FAM_FOUT); GEMM_TRY(launch_gemm_splitk<T>(s, zcur, Kf, WT(P.wout), Kf, M, D, Kf, SPLITS, partial)); }
+            ProfScope ps(m, s, FAM_LN);
+            hipLaunchKernelGGL((splitk_reduce_ln_kernel<T>), dim3(ceil_div(M, 16)), dim3(256), 0, s, partial, SPLITS, (size_t)M * D, F32(P.bout), M, D,
+                               F32(P.layers[0].ffn[0].ln_g), F32(P.layers[0].ffn[0].ln_b), x, xn);
+            LAUNCH_CHECK();
+        } else if ((rc = gemm_to_stream(FAM_FOUT, zcur, Kf, P.wout, P.bout, 1.0f, false, P.layers[0].ffn[0].ln_g, P.layers[0].ffn[0].ln_b, -1, -1))) {
+            return rc;
+        }
+    }
     if ((rc = tap<float>(m, s, "front.y", x, (size_t)M * D))) return rc;
 
     if (m->vtN != N || m->vtT != Tn) {   // pad dims of q, k, v must read as zero for this shape
@@ -739,23 +776,27 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     if constexpr (sizeof(T) == 2) {
         if (rowln && chain_supported(D, ff, dh) && !m->debug && !m->no_chain) {
             // ---- row-local chains (chain.hip.h): 4 launches per block
+            const bool c96 = !m->chain48;
+            const unsigned char *CW = c96 ? m->packed : B;       // chain weights: fragment-major copies or the row-major blob
+            auto CWT = [&](size_t off) { return (const bf16_t *)(CW + off); };
+            auto launch = [&](const ChainArgs &a) { return c96 ? launch_chain96(s, a) : launch_chain(s, a, ff); };
             auto base = [&]() { ChainArgs a{}; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
             auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
-                ChainStage st{}; st.kind = ST_ROWLN; st.W = (const bf16_t *)WT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha; st.has_resid = 1;
+                ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha; st.has_resid = 1;
                 st.g1 = F32(g1); st.b1 = F32(b1); return st; };
             auto st_ffn = [&](const FfnW &fw, size_t g1, size_t b1, long g2, long b2) {
-                ChainStage st{}; st.kind = ST_FFN; st.W = (const bf16_t *)WT(fw.w1); st.W2 = (const bf16_t *)WT(fw.w2); st.bias = F32(fw.b1); st.bias2 = F32(fw.b2);
+                ChainStage st{}; st.kind = ST_FFN; st.W = CWT(fw.w1); st.W2 = CWT(fw.w2); st.bias = F32(fw.b1); st.bias2 = F32(fw.b2);
                 st.N = ff; st.alpha = ffr; st.has_resid = 1; st.g1 = F32(g1); st.b1 = F32(b1);
                 st.g2 = g2 >= 0 ? F32((size_t)g2) : nullptr; st.b2 = b2 >= 0 ? F32((size_t)b2) : nullptr; return st; };
             auto st_qkv = [&](const LayerW &lw) {
-                ChainStage st{}; st.kind = ST_QKV; st.W = (const bf16_t *)WT(lw.wqkv); st.bias = F32(lw.bqkv); st.N = 3 * D;
+                ChainStage st{}; st.kind = ST_QKV; st.W = CWT(lw.wqkv); st.bias = F32(lw.bqkv); st.N = 3 * D;
                 st.q = (bf16_t *)q; st.k = (bf16_t *)k; st.v = (bf16_t *)v; return st; };
             {   // first block's FFN + q/k/v projection on the frontend output
                 ChainArgs a = base(); a.A0 = (const bf16_t *)xn; a.nstages = 2;
                 a.st[0] = st_ffn(P.layers[0].ffn[0], P.layers[0].a_ln_g, P.layers[0].a_ln_b, -1, -1); a.st[0].store_x = 1;
                 a.st[1] = st_qkv(P.layers[0]);
                 ProfScope ps(m, s, FAM_CH_FIRST);
-                GEMM_TRY(launch_chain(s, a, ff));
+                GEMM_TRY(launch(a));
             }
             for (int l = 0; l < m->L; ++l) {
                 const LayerW &w = P.layers[l];
@@ -769,10 +810,10 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 {   // out-proj + residual + conv-module LayerNorm -> pointwise conv 1 + GLU
                     ChainArgs a = base(); a.A0 = (const bf16_t *)ctx; a.nstages = 2;
                     a.st[0] = st_rowln(w.wo, w.bo, 1.0f, w.c_ln_g, w.c_ln_b); a.st[0].store_x = 1;
-                    ChainStage g{}; g.kind = ST_GLU; g.W = (const bf16_t *)WT(w.wpw1); g.bias = F32(w.bpw1); g.N = 2 * D; g.out = (bf16_t *)glu;
+                    ChainStage g{}; g.kind = ST_GLU; g.W = CWT(w.wpw1); g.bias = F32(w.bpw1); g.N = 2 * D; g.out = (bf16_t *)glu;
                     a.st[1] = g;
                     ProfScope ps(m, s, FAM_CH_A);
-                    GEMM_TRY(launch_chain(s, a, ff));
+                    GEMM_TRY(launch(a));
                 }
                 {
                     ProfScope ps(m, s, FAM_DW);
@@ -788,13 +829,14 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                         a.st[2] = st_ffn(nx.ffn[0], nx.a_ln_g, nx.a_ln_b, -1, -1); a.st[2].store_x = 1;
                         a.st[3] = st_qkv(nx);
                         a.nstages = 4;
+                        if (l == 5) a.stamps = m->stamps;
                         ProfScope ps(m, s, FAM_CH_B);
-                        GEMM_TRY(launch_chain(s, a, ff));
+                        GEMM_TRY(launch(a));
                     } else {
                         a.st[1] = st_ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, -1, -1); a.st[1].store_x = 1; a.st[1].store_xn = 1;
                         a.nstages = 2;
                         ProfScope ps(m, s, FAM_CH_LAST);
-                        GEMM_TRY(launch_chain(s, a, ff));
+                        GEMM_TRY(launch(a));
                     }
                 }
             }
@@ -863,6 +905,30 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     return COCR_OK;
 }
 
+// (Re)builds the fragment-major weight copies the 96-row chain kernels read.  Runs on `s` ahead of the forward's launches
+// (stream order covers a blob import issued on the same stream), never inside a graph capture.
+static bool uses_chain96(const cocr_model *m) {
+    return m->dtype == COCR_BF16 && gemm_rowln_supported<bf16_t>(m->D) && chain_supported(m->D, m->ff, m->dh) && !m->no_chain && !m->chain48;
+}
+static int ensure_packed(cocr_model *m, hipStream_t s) {
+    if (!uses_chain96(m) || !m->packed_stale) return COCR_OK;
+    if (!m->packed) HIP_TRY(hipMalloc((void **)&m->packed, m->plan.total));
+    const int D = m->D, ff = m->ff;
+    auto pack = [&](size_t off, int N, int K) {
+        hipLaunchKernelGGL(pack_frag_kernel, dim3(std::min(1024, ceil_div(N * K / 8, 256))), dim3(256), 0, s, (const bf16_t *)(m->blob + off),
+                           (bf16_t *)(m->packed + off), N, K);
+    };
+    for (const LayerW &w : m->plan.layers) {
+        for (int i = 0; i < 2; ++i) { pack(w.ffn[i].w1, ff, D); pack(w.ffn[i].w2, D, ff); }
+        pack(w.wqkv, 3 * D, D); pack(w.wo, D, D); pack(w.wpw1, 2 * D, D); pack(w.wpw2, D, D);
+    }
+    LAUNCH_CHECK();
+    m->packed_stale = false;
+    for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);     // (pointers unchanged, but keep replay and rebuild ordered simply)
+    m->graphs.clear(); m->graph_seen.clear();
+    return COCR_OK;
+}
+
 extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W, const int32_t *in_lens,
                             float *logits, int32_t *out_lens, void *stream) {
     if (!m || !lines || !logits) return fail(COCR_EINVAL, "null argument");
@@ -876,6 +942,7 @@ extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, in
     if (in_lens && out_lens)
         for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = ensure_packed(m, s))) return rc;
     auto run = [&]() -> int {
         if (m->dtype == COCR_BF16) {
             if (line_dtype == COCR_F32) return forward_impl<bf16_t, float>(m, (const float *)lines, N, H, W, logits, s);
@@ -1007,7 +1074,7 @@ extern "C" int cocr_dev_bench_gemm(int variant, int M, int N, int K, int iters, 
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, (unsigned short *)bias, (size_t)N, 4u, 1);
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, (unsigned short *)gam, (size_t)K, 5u, 1);
     HIP_TRY(hipMemset(O, 0, (size_t)M * N * 4));
-    GemmArgs<T> a{(const T *)A, K, (const T *)W, K, M, N, K};
+    GemmArgs<T> a{(const T *)A, K, (const T *)W, K, M, N, K, 0};
     EpiBiasAct<T, ACT_SILU> eh{(T *)O, N, bias, N};
     EpiResidual er{(float *)O, N, bias, 0.5f, N};
     EpiNull en{(float *)O};

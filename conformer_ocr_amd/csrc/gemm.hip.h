@@ -21,6 +21,7 @@
 #pragma once
 #include <algorithm>
 #include <set>
+#include <type_traits>
 
 #include "common.hip.h"
 
@@ -74,10 +75,12 @@ struct EpiStoreF32 {
     typedef float stage_t;
     static constexpr bool GLU = false;
     static constexpr bool ROWWISE = false;
-    float *out; int ldo; const float *bias; int N;
+    float *out; int ldo; const float *bias; int N;     // bias may be null (split-K partial sums)
+    size_t zstride = 0;                                // split-K: partial z goes to out + z * zstride
+    __device__ __forceinline__ EpiStoreF32 with_z(int z) const { EpiStoreF32 e = *this; e.out += (size_t)z * zstride; return e; }
     __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = v[i] + (n + i < N ? bias[n + i] : 0.f);
+        for (int i = 0; i < 4; ++i) r[i] = v[i] + ((bias && n + i < N) ? bias[n + i] : 0.f);
     }
     __device__ __forceinline__ void store(int m, int c, const float *src, int cnt) const {
         float *p = out + (size_t)m * ldo + c;
@@ -413,7 +416,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][NI], unsigned cha
 template <typename T> struct GemmArgs {
     const T *A; int lda;
     const T *W; int ldw;
-    int M, N, K;
+    int M, N, K;           // K of ONE split
+    int k_zstride;         // split-K: grid.y = number of splits; split z reads k in [z * k_zstride, z * k_zstride + K) and
+                           // writes through epi.with_z(z) (0 when unused)
 };
 
 __device__ __forceinline__ bf16x8 lds_frag_swz(const unsigned char *row, int kc, int g, int swz, bf16_t) {
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) 
     const int ltile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (ltile / gx) * BM, n0 = (ltile % gx) * BN;
     const int nk = K / BK;
+    if (p.k_zstride) { p.A += (size_t)blockIdx.y * p.k_zstride; p.W += (size_t)blockIdx.y * p.k_zstride; }
 
     auto issue = [&](int kt) {
         unsigned char *st = smem + (kt % NST) * STAGE;
@@ -496,7 +502,12 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) 
         }
     }
     __syncthreads();                                     // every wave is done reading the ring: reuse it for the staged tile
-    gemm_epilogue<BM, BN, MI, NI, Epi>(acc, smem, m0, n0, M, N, epi);
+    if constexpr (std::is_same<Epi, EpiStoreF32>::value) {
+        const EpiStoreF32 ez = epi.with_z(p.k_zstride ? blockIdx.y : 0);
+        gemm_epilogue<BM, BN, MI, NI, Epi>(acc, smem, m0, n0, M, N, ez);
+    } else {
+        gemm_epilogue<BM, BN, MI, NI, Epi>(acc, smem, m0, n0, M, N, epi);
+    }
 }
 
 // ---- register-staged kernel (any k tail) ---------------------------------------------------------------------
@@ -614,7 +625,7 @@ static inline hipError_t launch_stream_cfg(hipStream_t s, const GemmArgs<T> &a, 
 // Requirements (checked at model build): K % (16/sizeof(T)) == 0, lda/ldw multiples of 16 bytes, 16-byte aligned bases.
 template <typename T, typename Epi>
 static inline hipError_t launch_gemm(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, const Epi &epi) {
-    GemmArgs<T> a{A, lda, W, ldw, M, N, K};
+    GemmArgs<T> a{A, lda, W, ldw, M, N, K, 0};
     constexpr int BK = 128 / (int)sizeof(T);
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     if (K % BK == 0) {
@@ -717,7 +728,7 @@ __global__ __launch_bounds__(256) void gemm_rowln48_kernel(GemmArgs<T> p, Epi ep
 template <typename T> static inline bool gemm_rowln_supported(int N) { return N <= 256 && (N & 3) == 0; }
 template <typename T, typename Epi>
 static inline hipError_t launch_gemm_rowln(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, const Epi &epi) {
-    GemmArgs<T> a{A, lda, W, ldw, M, N, K};
+    GemmArgs<T> a{A, lda, W, ldw, M, N, K, 0};
     constexpr int BK = 128 / (int)sizeof(T);
     if (K % BK == 0) {
         const size_t lds = (size_t)3 * (64 + 256) * 128;          // >= the 48 x (256*4+16) staged tile
@@ -728,4 +739,21 @@ static inline hipError_t launch_gemm_rowln(hipStream_t s, const T *A, int lda, c
         return hipGetLastError();
     }
     return launch_stream_cfg<T, 32, 256, Epi>(s, a, epi);
+}
+
+// Split-K product for the frontend output linear (M x 256 x 6144): `splits` partial sums [z][M][N] fp32 (no bias), summed by
+// splitk_reduce_ln_kernel.  One launch, grid.y = splits; 128 x 128 tiles.
+template <typename T>
+static inline hipError_t launch_gemm_splitk(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, int splits, float *partial) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    if (K % (splits * BK)) return hipErrorInvalidValue;
+    GemmArgs<T> a{A, lda, W, ldw, M, N, K / splits, K / splits};
+    EpiStoreF32 e{partial, N, nullptr, N};
+    e.zstride = (size_t)M * N;
+    const size_t lds = std::max((size_t)2 * (128 + 128) * 128, epi_lds_bytes<EpiStoreF32, 128, 128>());
+    auto kern = gemm_ring_kernel<T, 128, 128, 2, EpiStoreF32>;
+    hipError_t err = raise_lds_limit((const void *)kern, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(N, 128) * ceil_div(M, 128), splits), dim3(256), lds, s, a, e);
+    return hipGetLastError();
 }

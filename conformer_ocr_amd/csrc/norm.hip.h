@@ -114,3 +114,47 @@ static inline void launch_layernorm(hipStream_t s, const float *x, int M, int D,
     else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
     else hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
 }
+
+// x = sum_z partial[z] + bias (split-K partial sums of the frontend output linear), then LayerNorm -> xn: one wave per 4 rows,
+// D <= 256 (one float4 chunk per lane).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float *__restrict__ partial, int splits, size_t zstride, const float *__restrict__ bias,
+                                                               int M, int D, const float *__restrict__ g1, const float *__restrict__ b1,
+                                                               float *__restrict__ x, T *__restrict__ xn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * 4;
+    if (row0 >= M) return;
+    const int nchunk = D >> 2, c = lane, cc = min(c, nchunk - 1);
+    const float inv_d = 1.0f / (float)D;
+    const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias + 4 * cc);
+    f32x4 v[4];
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t off = (size_t)min(row0 + r, M - 1) * D + 4 * cc;
+        f32x4 t = bb;
+        for (int z = 0; z < splits; ++z) t += *reinterpret_cast<const f32x4 *>(partial + z * zstride + off);
+        if (c >= nchunk) t = (f32x4){0, 0, 0, 0};
+        v[r] = t;
+        s[r] = t[0] + t[1] + t[2] + t[3];
+        if (row0 + r < M && c < nchunk) *reinterpret_cast<f32x4 *>(x + (size_t)(row0 + r) * D + 4 * c) = t;
+    }
+    const f32x4 ga = c < nchunk ? *reinterpret_cast<const f32x4 *>(g1 + 4 * cc) : (f32x4){0, 0, 0, 0};
+    const f32x4 be = c < nchunk ? *reinterpret_cast<const f32x4 *>(b1 + 4 * cc) : (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float mean = wave_sum(s[r]) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = c < nchunk ? v[r][e] - mean : 0.f; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+        if (row0 + r < M && c < nchunk) {
+            T *p = xn + (size_t)(row0 + r) * D + 4 * c;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[r][e] - mean) * rstd * ga[e] + be[e];
+            if constexpr (sizeof(T) == 2) { bf16x4 w = {(T)o[0], (T)o[1], (T)o[2], (T)o[3]}; *reinterpret_cast<bf16x4 *>(p) = w; }
+            else { *reinterpret_cast<f32x4 *>(p) = (f32x4){o[0], o[1], o[2], o[3]}; }
+        }
+    }
+}
