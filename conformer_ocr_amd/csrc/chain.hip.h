@@ -45,6 +45,8 @@ struct ChainArgs {
     float *x;              // fp32 residual stream (M, 256)
     bf16_t *xn;            // normalised operand (M, 256), written when a stage asks for it
     int M, nstages;
+    const bf16_t *dw_in;   // 96-row form with the depthwise-conv prologue: GLU output (M, 256); A0 unused
+    const float *dw_w, *dw_b;      // BatchNorm-folded depthwise taps [k][256] and bias [256]
     unsigned long long *stamps;   // dev: cycle stamps of workgroup 0 / wave 0 (COCR_CHAIN_STAMPS), else null
     int dh, dhp, heads, T_, Tp;       // attention layout of the QKV stage
     ChainStage st[4];
@@ -356,7 +358,10 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int K0, int K1, int K2, int K3>
+// DWK != 0: the chain starts with the conv module's depthwise conv (kernel DWK, zero padding, BatchNorm folded) + SiLU on the
+// GLU output (convolution.py:140-142), computed for the workgroup's 96 rows from a (96 + DWK - 1)-row window in LDS, result
+// written straight into the operand image -- one launch and one (M, 256) round trip less per block.
+template <int DWK, int K0, int K1, int K2, int K3>
 __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     typedef bf16_t T;
     constexpr int D = 256, BMC = 96, MT = 6, KC1 = D / 32;
@@ -380,12 +385,23 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
         __builtin_amdgcn_s_barrier();
     };
 
-    // ---- first operand tile -> LDS image: 4 panels x 12 row groups of 8 rows = 48 wave-instructions (6 per wave)
+    constexpr int DWPAD = DWK ? (DWK - 1) / 2 : 0, DWROWS = BMC + 2 * DWPAD;
+    if constexpr (DWK == 0) {
+        // ---- first operand tile -> LDS image: 4 panels x 12 row groups of 8 rows = 48 wave-instructions (6 per wave)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int id = wave + 8 * i, pnl = id / 12, rg = id - pnl * 12, row = rg * 8 + lrow;
-        const T *src = p.A0 + (size_t)min(m0 + row, M - 1) * D + pnl * 64 + ((cpos ^ (row & 7)) * 8);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xa + pnl * PANEL + rg * 1024), 16, 0, 0);
+        for (int i = 0; i < 6; ++i) {
+            const int id = wave + 8 * i, pnl = id / 12, rg = id - pnl * 12, row = rg * 8 + lrow;
+            const T *src = p.A0 + (size_t)min(m0 + row, M - 1) * D + pnl * 64 + ((cpos ^ (row & 7)) * 8);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xa + pnl * PANEL + rg * 1024), 16, 0, 0);
+        }
+    } else {
+        // ---- depthwise window: rows m0 - PAD .. m0 + 96 + PAD - 1 of the GLU output (addresses clamped; frames outside the
+        // row's own line are excluded by the tap range below), [row][512 B] at hs: one wave-instruction = 2 rows
+        static_assert(DWROWS % 2 == 0, "window rows are loaded in pairs");
+        for (int q2 = wave; q2 < DWROWS / 2; q2 += 8) {
+            const int j = 2 * q2 + (lane >> 5), mrow = min(max(m0 - DWPAD + j, 0), M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.dw_in + (size_t)mrow * D + (lane & 31) * 8), (lds_ptr_t)(hs + q2 * 1024), 16, 0, 0);
+        }
     }
     // ---- weight ring: the first step's 16 fragments
     bf16x8 ring[16];
@@ -398,9 +414,11 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     // row -> offset of its (batch, frame) in the q / k / v layouts [B][h][Tp][dhp] (the q/k/v stage's scatter would otherwise
     // divide per 16-byte store)
     long long *rowoff = reinterpret_cast<long long *>(smem + 3 * IMG + 8192);
+    int *tpos = reinterpret_cast<int *>(smem + 3 * IMG + 8192 + 768);        // frame index of each row inside its line
     if (tid < BMC) {
         const int m = min(m0 + tid, M - 1), b = m / p.T_, t = m - b * p.T_;
         rowoff[tid] = ((long long)b * p.heads * p.Tp + t) * p.dhp;
+        tpos[tid] = t;
     }
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // the operand DMAs (older than the 16 ring loads) have landed
     lds_fence_barrier0();
@@ -415,6 +433,58 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     auto stamp = [&]() {};
 #endif
     stamp();
+    if constexpr (DWK != 0) {
+        // thread = one channel pair x 24 rows (3 groups of 8); a wave's lanes share their rows, so the boundary test is uniform.
+        // Accumulation order per output: bias, then taps ascending (as the stand-alone kernel).
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+        const int cp = tid & 127, c = 2 * cp, rq = __builtin_amdgcn_readfirstlane(tid >> 7);
+        f32x2 wt[DWK];
+#pragma unroll
+        for (int tau = 0; tau < DWK; ++tau) wt[tau] = *reinterpret_cast<const f32x2 *>(p.dw_w + (size_t)tau * D + c);
+        const f32x2 bias = *reinterpret_cast<const f32x2 *>(p.dw_b + c);
+        const int T_ = p.T_;
+#pragma unroll 1
+        for (int grp = 0; grp < 3; ++grp) {
+            const int r0 = 24 * rq + 8 * grp;
+            const int t0 = __builtin_amdgcn_readfirstlane(tpos[r0]);
+            f32x2 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = bias;
+            const unsigned char *wbase = hs + (size_t)r0 * 512 + c * 2;
+            if (t0 >= DWPAD && t0 + 7 + DWPAD < T_) {              // all 8 rows inside one line, full tap range
+#pragma unroll
+                for (int rin = 0; rin < 8 + DWK - 1; ++rin) {
+                    const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * 512);
+                    const f32x2 xf = {(float)xv[0], (float)xv[1]};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int tau = rin - i;
+                        if (tau >= 0 && tau < DWK) acc[i] = __builtin_elementwise_fma(wt[tau], xf, acc[i]);
+                    }
+                }
+            } else {                                               // near a line end: tap tau of row i is in range iff 0 <= t_i + tau - PAD < T
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ti = __builtin_amdgcn_readfirstlane(tpos[r0 + i]);
+#pragma unroll
+                    for (int tau = 0; tau < DWK; ++tau) {
+                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + (i + tau) * 512);
+                        const bool ok = (unsigned)(ti + tau - DWPAD) < (unsigned)T_;
+                        const f32x2 xf = {ok ? (float)xv[0] : 0.f, ok ? (float)xv[1] : 0.f};
+                        acc[i] = __builtin_elementwise_fma(wt[tau], xf, acc[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = r0 + i;
+                const bf16x2 o = {(T)silu_f(acc[i][0]), (T)silu_f(acc[i][1])};
+                *reinterpret_cast<bf16x2 *>(xa + (c >> 6) * PANEL + row * 128 + ((((c & 63) >> 3) ^ (row & 7)) << 4) + (c & 7) * 2) = o;
+            }
+        }
+        lds_fence_barrier0();                                // operand image complete; the window (hs) is free
+    }
     // One step: acc[96 rows][32 columns of this wave] += image . ring ; ring <- the 16 fragments at `nxt`.  `side(kk)` is
     // independent VALU work folded into the k-step (the MFMA pipe runs beside it).
     auto step = [&](const unsigned char *img, f32x4 (&acc)[MT][2], const T *nxt, auto &&side) {
@@ -689,10 +759,10 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     run_stage(std::integral_constant<int, K3>{}, p.st[3], first_slice(0));
 }
 
-template <int K0, int K1, int K2, int K3>
+template <int DWK, int K0, int K1, int K2, int K3>
 static inline hipError_t launch_chain96_cfg(hipStream_t s, const ChainArgs &a) {
-    const size_t lds = (size_t)3 * 4 * 96 * 128 + 4096 + 4096 + 1024;      // operand image, 2 hidden images (+ slack), LayerNorm parameters, row offsets
-    auto kern = chain96_kernel<K0, K1, K2, K3>;
+    const size_t lds = (size_t)3 * 4 * 96 * 128 + 4096 + 4096 + 2048;      // operand image, 2 hidden images (+ slack), LayerNorm parameters, row offsets + frame indices
+    auto kern = chain96_kernel<DWK, K0, K1, K2, K3>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, 96)), dim3(512), lds, s, a);
@@ -702,9 +772,14 @@ static inline hipError_t launch_chain96_cfg(hipStream_t s, const ChainArgs &a) {
 // the chain shapes the forward uses; stage weights point at the fragment-major copies
 static inline hipError_t launch_chain96(hipStream_t s, const ChainArgs &a) {
     const int k0 = a.st[0].kind, k1 = a.nstages > 1 ? a.st[1].kind : -1, k2 = a.nstages > 2 ? a.st[2].kind : -1, k3 = a.nstages > 3 ? a.st[3].kind : -1;
-    if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_chain96_cfg<ST_FFN, ST_QKV, -1, -1>(s, a);
-    if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_chain96_cfg<ST_ROWLN, ST_GLU, -1, -1>(s, a);
-    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a);
-    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<ST_ROWLN, ST_FFN, -1, -1>(s, a);
+    if (a.dw_in) {                       // depthwise-conv prologue (kernel 31): the chains that follow the conv module's GLU
+        if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<31, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a);
+        if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<31, ST_ROWLN, ST_FFN, -1, -1>(s, a);
+        return hipErrorInvalidValue;
+    }
+    if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_chain96_cfg<0, ST_FFN, ST_QKV, -1, -1>(s, a);
+    if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_chain96_cfg<0, ST_ROWLN, ST_GLU, -1, -1>(s, a);
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<0, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a);
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<0, ST_ROWLN, ST_FFN, -1, -1>(s, a);
     return hipErrorInvalidValue;
 }

@@ -24,6 +24,7 @@
 #include "gemm.hip.h"
 #include "ffn.hip.h"
 #include "chain.hip.h"
+#include "frontend.hip.h"
 #include "norm.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
@@ -87,6 +88,7 @@ struct cocr_model {
     // fragment-major copies of the chain kernels' weight matrices (chain.hip.h), at the blob's offsets; derived from the blob,
     // rebuilt before the next forward whenever the blob may have changed (finalize, import, cocr_weight_blob handed out)
     unsigned char *packed = nullptr;
+    bf16_t *fpack = nullptr;     // fused frontend kernel (frontend.hip.h): conv.0 A-fragments, then the depthwise block-diagonal B-fragments
     bool packed_stale = true;
     // workspace
     int capN = 0, capW = 0;
@@ -110,6 +112,9 @@ struct cocr_model {
     std::vector<GraphEntry> graphs, graph_seen;
     bool debug = false;
     unsigned long long *stamps = nullptr;   // COCR_CHAIN_STAMPS=1 (dev): host-visible cycle stamps of one chain launch, printed at destroy
+    bool no_front96 = false;     // COCR_NO_FRONT96=1: frontend conv stages as separate kernels (A/B)
+    bool no_conv_mfma = false;   // COCR_NO_CONV_MFMA=1: the all-VALU fp32 frontend conv kernel also in bf16 mode (A/B)
+    bool no_dw_fuse = false;     // COCR_NO_DW_FUSE=1: depthwise conv as its own launch (A/B)
     bool chain48 = false;        // COCR_CHAIN48=1: the 48-row LDS-DMA chain kernels instead of the 96-row register-streamed ones (A/B)
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
@@ -162,6 +167,9 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CHAIN"); m->no_chain = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN48"); m->chain48 = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_NO_FRONT96"); m->no_front96 = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_STAMPS"); if (e && e[0] == '1') { (void)hipHostMalloc((void **)&m->stamps, 256 * 8); memset(m->stamps, 0, 256 * 8); } }
     int f = hp->height;
     for (int i = 0; i < snum; ++i) { f = out_len1(f); m->feats.push_back(f); }
@@ -222,10 +230,13 @@ extern "C" void cocr_destroy(cocr_model *m) {
     clear_taps(m);
     if (m->blob) (void)hipFree(m->blob);
     if (m->packed) (void)hipFree(m->packed);
+    if (m->fpack) (void)hipFree(m->fpack);
     if (m->stamps) {
         (void)hipDeviceSynchronize();
         fprintf(stderr, "chain stamps (cycles since first):");
-        for (int i = 1; i < 256 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[0]);
+        for (int i = 1; i < 128 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[0]);
+        fprintf(stderr, "\nfrontend stamps:");
+        for (int i = 129; i < 256 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[128]);
         fprintf(stderr, "\n");
         (void)hipHostFree(m->stamps);
     }
@@ -347,6 +358,7 @@ static int alloc_blob(cocr_model *m, int dtype) {
     HIP_TRY(hipSetDevice(m->device));
     if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
     if (m->packed) { (void)hipFree(m->packed); m->packed = nullptr; }
+    if (m->fpack) { (void)hipFree(m->fpack); m->fpack = nullptr; }
     m->packed_stale = true;
     m->plan = make_plan(m, dtype);
     m->dtype = dtype;
@@ -655,6 +667,8 @@ static hipError_t launch_attention(hipStream_t s, dim3 grid, const T *q, const T
     return hipGetLastError();
 }
 
+static bool uses_frontend96(const cocr_model *m);
+
 template <typename T, typename TIn>
 static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, float *logits, hipStream_t s) {
     const BlobPlan &P = m->plan;
@@ -667,19 +681,42 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
 
     // ---- frontend: conv.0 + ReLU + depthwise conv.2 fused, then pointwise conv.3 + ReLU as a GEMM over channels
     T *za = (T *)m->z_a, *zb = (T *)m->z_b;
+    bool front_fused = false;
+    if constexpr (sizeof(T) == 2) {
+        if (uses_frontend96(m)) {                        // conv.0 + ReLU + depthwise conv.2 + pointwise conv.3 + ReLU in one kernel (frontend.hip.h)
+            ProfScope ps(m, s, FAM_CONV12);
+            const size_t n0 = (size_t)(C / 16) * 64 * 4;
+            GEMM_TRY(launch_frontend96<TIn>(s, lines, N, H, W, T1, F1, T2, m->fpack, F32(P.b0), m->fpack + n0, F32(P.stages[0].dw_b),
+                                            (const bf16_t *)(m->packed + P.stages[0].pw_w), F32(P.stages[0].pw_b), (bf16_t *)zb, m->stamps ? m->stamps + 128 : nullptr));
+            front_fused = true;
+            if ((rc = tap<T>(m, s, "front.z3", zb, (size_t)N * T2 * F2 * C))) return rc;      // (Z2 does not exist on this path)
+        }
+    }
+    if (!front_fused) {
     {
         ProfScope ps(m, s, FAM_CONV12);
-        const int TB = std::max(1, 512 / C);                 // 256 threads = TB time steps x C/2 channel pairs
-        const size_t lds = (size_t)(4 * TB + 3) * ((H + 11) & ~3) * 4;
-        hipLaunchKernelGGL((frontend_conv12_kernel<T, TIn>), dim3(ceil_div(T2, TB), N), dim3(256), lds, s, lines, H, W, T1, F1, T2, F2, C,
-                           F32(P.w0), F32(P.b0), F32(P.stages[0].dw_w), F32(P.stages[0].dw_b), za, TB);
-        LAUNCH_CHECK();
+        bool done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (C % 64 == 0 && !m->no_conv_mfma) {               // conv.0 on the matrix cores (conv.hip.h)
+                GEMM_TRY(launch_conv12_mfma<TIn>(s, lines, N, H, W, T1, F1, T2, F2, C, F32(P.w0), F32(P.b0), F32(P.stages[0].dw_w), F32(P.stages[0].dw_b),
+                                                 (bf16_t *)za));
+                done = true;
+            }
+        }
+        if (!done) {
+            const int TB = std::max(1, 512 / C);                 // 256 threads = TB time steps x C/2 channel pairs
+            const size_t lds = (size_t)(4 * TB + 3) * ((H + 11) & ~3) * 4;
+            hipLaunchKernelGGL((frontend_conv12_kernel<T, TIn>), dim3(ceil_div(T2, TB), N), dim3(256), lds, s, lines, H, W, T1, F1, T2, F2, C,
+                               F32(P.w0), F32(P.b0), F32(P.stages[0].dw_w), F32(P.stages[0].dw_b), za, TB);
+            LAUNCH_CHECK();
+        }
     }
     if ((rc = tap<T>(m, s, "front.z2", za, (size_t)N * T2 * F2 * C))) return rc;
     {
         ProfScope ps(m, s, FAM_FPW);
         EpiBiasAct<T, ACT_RELU> epi{zb, C, F32(P.stages[0].pw_b), C};
         GEMM_TRY(launch_gemm<T>(s, za, C, WT(P.stages[0].pw_w), C, N * T2 * F2, C, C, epi));
+    }
     }
     if ((rc = tap<T>(m, s, "front.z3", zb, (size_t)N * T2 * F2 * C))) return rc;
     int Tc = T2, Fc = F2;
@@ -815,13 +852,15 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                     ProfScope ps(m, s, FAM_CH_A);
                     GEMM_TRY(launch(a));
                 }
-                {
+                const bool dw_fused = c96 && m->ksz == 31 && !m->no_dw_fuse;      // depthwise conv as the chain's prologue
+                if (!dw_fused) {
                     ProfScope ps(m, s, FAM_DW);
                     launch_dwconv<T>(s, glu, N, Tn, D, m->ksz, F32(w.dww), F32(w.dwb), dwo);
                     LAUNCH_CHECK();
                 }
-                {   // pointwise conv 2 + residual + LayerNorm -> FFN 2 (+ closing LayerNorm [+ next block's]) [-> next block's FFN 1 -> its q/k/v]
+                {   // [depthwise conv + BN + SiLU ->] pointwise conv 2 + residual + LayerNorm -> FFN 2 (+ closing LayerNorm [+ next block's]) [-> next block's FFN 1 -> its q/k/v]
                     ChainArgs a = base(); a.A0 = (const bf16_t *)dwo;
+                    if (dw_fused) { a.dw_in = (const bf16_t *)glu; a.dw_w = F32(w.dww); a.dw_b = F32(w.dwb); }
                     a.st[0] = st_rowln(w.wpw2, w.bpw2, 1.0f, w.ffn[1].ln_g, w.ffn[1].ln_b);
                     if (l + 1 < m->L) {
                         const LayerW &nx = P.layers[l + 1];
@@ -910,17 +949,28 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
 static bool uses_chain96(const cocr_model *m) {
     return m->dtype == COCR_BF16 && gemm_rowln_supported<bf16_t>(m->D) && chain_supported(m->D, m->ff, m->dh) && !m->no_chain && !m->chain48;
 }
+static bool uses_frontend96(const cocr_model *m) {
+    return m->dtype == COCR_BF16 && m->snum == 2 && frontend96_supported(m->C, m->feats[0], m->feats[1], m->H) && !m->no_front96;
+}
 static int ensure_packed(cocr_model *m, hipStream_t s) {
-    if (!uses_chain96(m) || !m->packed_stale) return COCR_OK;
+    if ((!uses_chain96(m) && !uses_frontend96(m)) || !m->packed_stale) return COCR_OK;
     if (!m->packed) HIP_TRY(hipMalloc((void **)&m->packed, m->plan.total));
-    const int D = m->D, ff = m->ff;
+    const int D = m->D, ff = m->ff, C = m->C;
     auto pack = [&](size_t off, int N, int K) {
         hipLaunchKernelGGL(pack_frag_kernel, dim3(std::min(1024, ceil_div(N * K / 8, 256))), dim3(256), 0, s, (const bf16_t *)(m->blob + off),
                            (bf16_t *)(m->packed + off), N, K);
     };
-    for (const LayerW &w : m->plan.layers) {
-        for (int i = 0; i < 2; ++i) { pack(w.ffn[i].w1, ff, D); pack(w.ffn[i].w2, D, ff); }
-        pack(w.wqkv, 3 * D, D); pack(w.wo, D, D); pack(w.wpw1, 2 * D, D); pack(w.wpw2, D, D);
+    if (uses_chain96(m))
+        for (const LayerW &w : m->plan.layers) {
+            for (int i = 0; i < 2; ++i) { pack(w.ffn[i].w1, ff, D); pack(w.ffn[i].w2, D, ff); }
+            pack(w.wqkv, 3 * D, D); pack(w.wo, D, D); pack(w.wpw1, 2 * D, D); pack(w.wpw2, D, D);
+        }
+    if (uses_frontend96(m)) {
+        pack(m->plan.stages[0].pw_w, C, C);
+        const size_t n0 = (size_t)(C / 16) * 64 * 4, n2 = (size_t)(C / 16) * 5 * 64 * 8;
+        if (!m->fpack) HIP_TRY(hipMalloc((void **)&m->fpack, (n0 + n2) * sizeof(bf16_t)));
+        hipLaunchKernelGGL(frontend_pack_kernel, dim3(ceil_div((int)n2, 256)), dim3(256), 0, s, (const float *)(m->blob + m->plan.w0),
+                           (const float *)(m->blob + m->plan.stages[0].dw_w), m->fpack, m->fpack + n0, C);
     }
     LAUNCH_CHECK();
     m->packed_stale = false;

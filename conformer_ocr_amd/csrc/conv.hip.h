@@ -95,6 +95,124 @@ __global__ __launch_bounds__(256) void frontend_conv12_kernel(const TIn *__restr
     }
 }
 
+// ---- frontend F1+F2, bf16 mode, C % 64 == 0: the first conv on the matrix cores ------------------------------
+// Z1 = relu(conv 3x3 s2 of the 1-channel line) is a (pixels x 9) x (9 x C) product: K padded to 16 as k = 4 dt + df
+// (df = 3 and dt = 3 carry zero weights), so a lane's 4 k-values are 4 CONSECUTIVE image rows of one image column --
+// two 4-byte LDS reads from the transposed bf16 line tile, no im2col buffer.  v_mfma_f32_16x16x16_bf16 with the
+// channels on the row side: a lane ends up with 4 consecutive channels of one Z1 pixel = one 8-byte LDS store into
+// the Z1 tile [column][row][64 channels] (bf16, ReLU applied, zero outside the valid Z1 range = the second conv's
+// padding).  The depthwise 3x3 s2 that follows is VALU work on that tile: a thread owns a channel pair and walks f
+// with the previous Z1 row pair in registers (6 LDS reads + 9 packed FMAs per output pair).  Workgroup = 4 frames
+// of one line x all channels, 64 channels per pass.  Arithmetic: bf16 pixels and conv.0 weights, fp32 accumulate;
+// Z1 rounded to bf16; depthwise in fp32 (the VALU kernel above keeps everything fp32 -- fp32 mode uses that one).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void frontend_conv12_mfma_kernel(const TIn *__restrict__ X, int H, int W, int T1, int F1, int Tn, int F, int C,
+                                                                   const float *__restrict__ w0, const float *__restrict__ b0,
+                                                                   const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                   bf16_t *__restrict__ Z2, int HS, int ZR) {
+    constexpr int TB = 4, NA = 2 * TB + 1, NCOL = 4 * TB + 4, ZC = 68;    // ZC: padded channel stride of the Z1 tile (conflict-free 8-byte stores)
+    extern __shared__ __attribute__((aligned(16))) unsigned char c12_smem[];
+    bf16_t *xs = reinterpret_cast<bf16_t *>(c12_smem);                    // [NCOL][HS]: LDS row rr <-> image row rr - 1; zero outside the image
+    bf16_t *z1 = xs + NCOL * HS;                                          // [NA][ZR][ZC]: row zr <-> f1 = zr - 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, t0 = blockIdx.x * TB;
+    const int col0 = 4 * t0 - 3;
+    const TIn *Xb = X + (size_t)b * H * W;
+    for (int i = tid; i < NCOL * HS; i += 256) {
+        const int ci = i / HS, rr = i - ci * HS;
+        const int w = min(max(col0 + ci, 0), W - 1), r = min(max(rr - 1, 0), H - 1);      // clamped address + select
+        const float v = pixel_to_f32<TIn>(Xb[(size_t)r * W + w]);
+        xs[i] = (bf16_t)((col0 + ci >= 0 && col0 + ci < W && rr >= 1 && rr <= H) ? v : 0.0f);
+    }
+    // rows zr = 0 (f1 = -1) and zr > F1 of the Z1 tile are the second conv's zero padding: written once
+    for (int i = tid; i < NA * ZC; i += 256) {
+        const int a = i / ZC, c = i - a * ZC;
+        z1[(a * ZR) * ZC + c] = (bf16_t)0.0f;
+        for (int zr = F1 + 1; zr < ZR; ++zr) z1[(a * ZR + zr) * ZC + c] = (bf16_t)0.0f;
+    }
+    __syncthreads();
+
+    const int FT = (F1 + 15) >> 4;                         // 16-pixel tiles per Z1 column
+    const int ntile = NA * FT;
+    const int cp = tid & 31, grp = tid >> 5, tl = grp >> 1, fh = grp & 1;
+    const int FH = (F + 1) >> 1, fbeg = fh * FH, fend = min(F, fbeg + FH);
+    const int t = t0 + tl;
+    for (int cb = 0; cb < C; cb += 64) {
+        // ---- conv.0 on the matrix cores: wave takes pixel tiles wave, wave + 4, ...; 4 channel tiles each
+        s16x4 wf[4];
+        f32x4 bias[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int ch = cb + 16 * nt + r16;
+            bf16x4 v = {(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
+            if (g < 3) { v[0] = (bf16_t)w0[ch * 9 + 3 * g]; v[1] = (bf16_t)w0[ch * 9 + 3 * g + 1]; v[2] = (bf16_t)w0[ch * 9 + 3 * g + 2]; }
+            wf[nt] = __builtin_bit_cast(s16x4, v);
+            bias[nt] = *reinterpret_cast<const f32x4 *>(b0 + cb + 16 * nt + 4 * g);
+        }
+        for (int mt = wave; mt < ntile; mt += 4) {
+            const int a = mt / FT, f1 = 16 * (mt - a * FT) + r16;            // this lane's pixel: Z1 column a, row f1
+            const int t1 = 2 * t0 - 1 + a;
+            const bf16_t *px = xs + (2 * a + g) * HS + 2 * f1;               // image rows 2 f1 - 1 .. 2 f1 + 2 of image column col0 + 2a + dt
+            const unsigned lo = *reinterpret_cast<const unsigned *>(px), hi = *reinterpret_cast<const unsigned *>(px + 2);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const s16x4 pf = __builtin_bit_cast(s16x4, (u32x2){lo, hi});
+            const bool valid = t1 >= 0 && t1 < T1 && f1 < F1;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[nt], pf, bias[nt], 0, 0, 0);
+                bf16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (bf16_t)(valid ? fmaxf(acc[q], 0.0f) : 0.0f);
+                if (f1 + 1 < ZR) *reinterpret_cast<bf16x4 *>(z1 + (a * ZR + f1 + 1) * ZC + 16 * nt + 4 * g) = o;
+            }
+        }
+        __syncthreads();
+        // ---- depthwise 3x3 s2 over the Z1 tile: thread = channel pair cp of this pass, frame tl, half of the f range
+        if (t < Tn) {
+            const int c = cb + 2 * cp;
+            f32x2 k2[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) k2[i] = (f32x2){w2[c * 9 + i], w2[(c + 1) * 9 + i]};
+            const f32x2 bias2 = {b2[c], b2[c + 1]};
+            const bf16_t *zc = z1 + (2 * tl * ZR) * ZC + 2 * cp;              // Z1 column a = 2 tl + dt, row zr = 2 f + df
+            auto ld = [&](int dt, int zr) {
+                const bf16x2 v = *reinterpret_cast<const bf16x2 *>(zc + (dt * ZR + zr) * ZC);
+                return (f32x2){(float)v[0], (float)v[1]};
+            };
+            f32x2 prev[3];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) prev[dt] = ld(dt, 2 * fbeg);
+            bf16_t *out = Z2 + (((size_t)b * Tn + t) * F) * C + c;
+            for (int f = fbeg; f < fend; ++f) {
+                f32x2 sacc = bias2;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    const f32x2 m = ld(dt, 2 * f + 1), n = ld(dt, 2 * f + 2);
+                    sacc += k2[dt * 3 + 0] * prev[dt] + k2[dt * 3 + 1] * m + k2[dt * 3 + 2] * n;
+                    prev[dt] = n;
+                }
+                const bf16x2 o = {(bf16_t)sacc[0], (bf16_t)sacc[1]};
+                *reinterpret_cast<bf16x2 *>(out + (size_t)f * C) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TIn>
+static inline hipError_t launch_conv12_mfma(hipStream_t s, const TIn *X, int N, int H, int W, int T1, int F1, int Tn, int F, int C, const float *w0,
+                                            const float *b0, const float *w2, const float *b2, bf16_t *Z2) {
+    const int FT = (F1 + 15) / 16;
+    const int HS = 2 * 16 * FT + 4;                         // image rows -1 .. 32 FT + 2 (zero beyond the image)
+    const int ZR = std::max(F1 + 1, 2 * F + 1) + 1;         // rows f1 = -1 .. max(F1, 2F) (zero outside [0, F1))
+    const size_t lds = ((size_t)20 * HS + (size_t)9 * ZR * 68) * 2;
+    hipLaunchKernelGGL((frontend_conv12_mfma_kernel<TIn>), dim3((Tn + 3) / 4, N), dim3(256), lds, s, X, H, W, T1, F1, Tn, F, C, w0, b0, w2, b2, Z2, HS, ZR);
+    return hipGetLastError();
+}
+
 // ---- extra depthwise 3x3 stride-2 stage on channel-last (B,T,F,C) -> (B,T2,F2,C), bias, no activation
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3s2_kernel(const T *__restrict__ in, int B, int Ti, int Fi, int To, int Fo, int C,

@@ -1,0 +1,239 @@
+// Frontend stages F1-F3 of a factor-4 Conv2dSubsampling in ONE kernel (bf16 mode, C = 256 channels, F = 24 output rows):
+//     Conv2d(1,C,3,s2,p1) + ReLU  ->  depthwise Conv2d(C,C,3,s2,p1)  ->  pointwise Conv2d(C,C,1) + ReLU
+// (reference conformer/convolution.py:192-205).  Neither the (B,C,W/2,H/2) tensor Z1 nor the depthwise output Z2 is
+// ever written: a workgroup owns 4 output frames of one line = 4 x 24 = 96 rows of the (B*T*F, C) activation, builds
+// them as the 96 x 256 bf16 operand image of the chain kernels (chain.hip.h) and runs the pointwise conv on it with the
+// same register-streamed weight ring.  All three convolutions run on the matrix cores:
+//   * conv.0: (pixels x 9) x (9 x C), K padded to 16 as k = 4 dt + df -- a lane's 4 k-values are 4 consecutive image rows
+//     of one image column: two 4-byte LDS reads from the transposed bf16 line tile (no im2col buffer); channels on the MFMA
+//     row side, so a lane holds 4 consecutive channels of one Z1 pixel = one 8-byte store into the Z1 tile;
+//   * depthwise conv.2: per block of 16 channels a (positions x (10 taps x 16 ch)) x ((10 taps x 16 ch) x 16 ch) product
+//     whose B operand is block-diagonal (w2[c][tap] on the diagonal, tap 9 = 0): 15/16 of the multiplies hit zeros, but
+//     the matrix pipe is otherwise idle here and the A operand is simply 8 consecutive channels of one Z1 pixel
+//     (one ds_read_b128 per lane and k-chunk) -- the VALU form costs 9 packed FMAs + 6 LDS reads + conversions per output pair;
+//   * pointwise conv.3: one step of the chain kernels' product (fragment-major weights, 16-fragment register ring).
+// Z1 is held 64 channels at a time ([9 columns][50 rows][64 ch] bf16 tile), 4 passes.  Arithmetic: bf16 operands (pixels,
+// all weights, Z1, Z2), fp32 accumulation -- the fp32 mode keeps the VALU kernel + GEMM.
+#pragma once
+#include "chain.hip.h"
+#include "conv.hip.h"
+
+// ---- weight images built once per model (cocr_api: ensure_packed) -----------------------------------------------
+// w0f: conv.0 A-fragments [16 channel tiles][64 lanes][4 bf16]: lane (r, g) = w0[16 nt + r][dt = g][df = 0..2], 0
+// dwf: depthwise B-fragments [16 blocks][5 k-chunks][64 lanes][8 bf16]: lane (r, g), element i <-> k = 32 chunk + 8 g + i
+//      = (tap = 2 chunk + (g >> 1), c' = 8 (g & 1) + i); value w2[16 blk + r][tap] where c' == r and tap < 9, else 0
+__global__ __launch_bounds__(256) void frontend_pack_kernel(const float *__restrict__ w0, const float *__restrict__ w2, bf16_t *__restrict__ w0f,
+                                                            bf16_t *__restrict__ dwf, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < (C / 16) * 64 * 4) {
+        const int e = i & 3, lane = (i >> 2) & 63, nt = i >> 8, r = lane & 15, g = lane >> 4;
+        w0f[i] = (bf16_t)((g < 3 && e < 3) ? w0[(16 * nt + r) * 9 + 3 * g + e] : 0.0f);
+    }
+    if (i < (C / 16) * 5 * 64 * 8) {
+        const int e = i & 7, lane = (i >> 3) & 63, chunk = (i >> 9) % 5, blk = i / (5 * 512), r = lane & 15, g = lane >> 4;
+        const int tap = 2 * chunk + (g >> 1), cc = 8 * (g & 1) + e;
+        dwf[i] = (bf16_t)((cc == r && tap < 9) ? w2[(16 * blk + r) * 9 + tap] : 0.0f);
+    }
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__ X, int H, int W, int T1, int F1, int Tn,
+                                                         const bf16_t *__restrict__ w0f, const float *__restrict__ b0,
+                                                         const bf16_t *__restrict__ dwf, const float *__restrict__ b2,
+                                                         const bf16_t *__restrict__ wpw,        // fragment-major (256, 256)
+                                                         const float *__restrict__ bpw, bf16_t *__restrict__ Z3, int HS, unsigned long long *stamps) {
+    typedef bf16_t T;
+    constexpr int C = 256, F = 24, TB = 4, BMC = TB * F, MT = 6, KC1 = C / 32;
+    constexpr int NA = 2 * TB + 1, NCOL = 4 * TB + 4, ZR = 2 * F + 2, ZC = 72;      // Z1 tile: rows zr = f1 + 1 in [0, 2F + 1], 64 channels + pad
+    constexpr int PANEL = BMC * 128, IMG = 4 * PANEL, OS = C * 2 + 16, SLICE = 16 * 512;
+    static_assert(BMC == 96, "operand image of the chain kernels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *xa = smem;                                             // 96 x 256 bf16 operand image (Z2)
+    T *z1 = reinterpret_cast<T *>(smem + IMG);                            // [NA][ZR][ZC]; later the bf16 output tile [96][OS]
+    T *xs = z1 + NA * ZR * ZC;                                            // [NCOL][HS] transposed line tile: row rr <-> image row rr - 1
+    unsigned char *prm = reinterpret_cast<unsigned char *>(xs + NCOL * HS);   // conv.0 A-fragments (8 KiB), b0 (1 KiB), b2 (1 KiB); 16-byte aligned (HS % 4 == 0)
+    const T *w0s = reinterpret_cast<const T *>(prm);
+    const float *b0s = reinterpret_cast<const float *>(prm + 8192), *b2s = b0s + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4, swz = r16 & 7;
+    const int b = blockIdx.y, t0 = blockIdx.x * TB;
+    const int col0 = 4 * t0 - 3;
+#ifdef COCR_CHAIN_STAMPS_BUILD
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (stamps && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) stamps[nstamp] = __builtin_readcyclecounter();
+        ++nstamp;
+    };
+#else
+    auto stamp = [&]() {};
+#endif
+    stamp();
+
+    // ---- line tile (transposed, bf16, zero outside the image): lanes run along the image row (coalesced), all of a thread's
+    // loads are issued before the first use; requested BEFORE the weight ring (loads return in order)
+    const TIn *Xb = X + (size_t)b * H * W;
+    constexpr int FILL = 4;                                 // NCOL * HS <= 4 * 512 (HS <= 100: checked by the launcher)
+    float fv[FILL];
+#pragma unroll
+    for (int u = 0; u < FILL; ++u) {
+        const int i = tid + 512 * u, rr = i / NCOL, ci = i - rr * NCOL;
+        const int w = min(max(col0 + ci, 0), W - 1), r = min(max(rr - 1, 0), H - 1);      // clamped address + select
+        const float v = pixel_to_f32<TIn>(Xb[(size_t)r * W + w]);
+        fv[u] = (col0 + ci >= 0 && col0 + ci < W && rr >= 1 && rr <= H) ? v : 0.0f;
+    }
+    // ---- conv.0 fragments and the two bias vectors -> LDS (10 wave-instructions of 1 KiB, asynchronous)
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w0f + wave * 512 + lane * 8), (lds_ptr_t)(prm + wave * 1024), 16, 0, 0);
+    if (wave < 2) __builtin_amdgcn_global_load_lds((gbl_ptr_t)((wave ? b2 : b0) + lane * 4), (lds_ptr_t)(prm + 8192 + wave * 1024), 16, 0, 0);
+    // ---- pointwise-conv weight ring: consumed last
+    bf16x8 ring[16];
+    {
+        const T *first = wpw + (size_t)wave * SLICE;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) ring[f] = *reinterpret_cast<const bf16x8 *>(first + f * 512 + lane * 8);
+    }
+    // the Z1 tile's zero rows (the depthwise conv's padding)
+    for (int i = tid; i < NA * ZC; i += 512) {
+        const int a = i / ZC, c = i - a * ZC;
+        z1[(a * ZR) * ZC + c] = (T)0.0f;
+        for (int zr = F1 + 1; zr < ZR; ++zr) z1[(a * ZR + zr) * ZC + c] = (T)0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < FILL; ++u) {
+        const int i = tid + 512 * u, rr = i / NCOL, ci = i - rr * NCOL;
+        if (i < NCOL * HS) xs[ci * HS + rr] = (T)fv[u];
+    }
+    stamp();
+    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");         // parameter DMAs landed (older than the 16 ring loads, which stay in flight)
+    __builtin_amdgcn_s_barrier();
+    stamp();
+
+    const int FT = (F1 + 15) >> 4, ntile = NA * FT;        // 16-pixel tiles of the Z1 columns
+    // depthwise work of this wave in every pass: channel block blk of the pass, position tiles mq, mq + 2, mq + 4
+    const int blk = wave & 3, mq = wave >> 2;
+    // conv.0 work of this wave in every pass: pixel tiles wave, wave + 8, ... (at most 4) x the pass's 4 channel tiles; the pixel
+    // fragments do not depend on the pass
+    s16x4 pf[4];
+    bool valid[4];
+    int zoff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int mt = min(wave + 8 * u, ntile - 1);
+        const int a = mt / FT, f1 = 16 * (mt - a * FT) + r16;            // this lane's pixel: Z1 column a, row f1
+        const int t1 = 2 * t0 - 1 + a;
+        const T *px = xs + (2 * a + g) * HS + 2 * f1;                    // image rows 2 f1 - 1 .. 2 f1 + 2 of image column col0 + 2a + dt
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        pf[u] = __builtin_bit_cast(s16x4, (u32x2){*reinterpret_cast<const unsigned *>(px), *reinterpret_cast<const unsigned *>(px + 2)});
+        valid[u] = t1 >= 0 && t1 < T1 && f1 < F1;
+        zoff[u] = (wave + 8 * u < ntile && f1 + 1 < ZR) ? (a * ZR + f1 + 1) * ZC : -1;
+    }
+    // depthwise fragments of (pass, blk): one pass ahead in registers
+    bf16x8 dwn[5];
+    auto request_dw = [&](int pass) {
+#pragma unroll
+        for (int ch = 0; ch < 5; ++ch) dwn[ch] = *reinterpret_cast<const bf16x8 *>(dwf + ((size_t)(4 * pass + blk) * 5 + ch) * 512 + lane * 8);
+    };
+    request_dw(0);
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int cb = 64 * pass;
+        bf16x8 dwb[5];
+#pragma unroll
+        for (int ch = 0; ch < 5; ++ch) dwb[ch] = dwn[ch];
+        if (pass < 3) request_dw(pass + 1);
+        const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(b2s + cb + 16 * blk + 4 * g);
+        s16x4 wf[4];
+        f32x4 bias0[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            wf[nt] = *reinterpret_cast<const s16x4 *>(w0s + ((size_t)((cb >> 4) + nt) * 64 + lane) * 4);
+            bias0[nt] = *reinterpret_cast<const f32x4 *>(b0s + cb + 16 * nt + 4 * g);
+        }
+        // ---- conv.0 + ReLU -> Z1 tile
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[nt], pf[u], bias0[nt], 0, 0, 0);
+                const bf16x4 o = {(T)fmaxf(acc[0], 0.0f), (T)fmaxf(acc[1], 0.0f), (T)fmaxf(acc[2], 0.0f), (T)fmaxf(acc[3], 0.0f)};
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 ob = __builtin_bit_cast(u32x2, o);
+                if (!valid[u]) ob = (u32x2){0u, 0u};                  // outside Z1: the depthwise conv's zero padding
+                if (zoff[u] >= 0) *reinterpret_cast<u32x2 *>(z1 + zoff[u] + 16 * nt + 4 * g) = ob;
+            }
+        stamp();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stamp();
+        // ---- depthwise conv.2 of channels cb + 16 blk .. +15 for position tiles mq, mq + 2, mq + 4 -> operand image
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int p = 16 * (mq + 2 * u) + r16, tl = p / F, f = p - tl * F;    // output position (frame tl, row f)
+            f32x4 acc = bias2;
+#pragma unroll
+            for (int ch = 0; ch < 5; ++ch) {
+                const int tap = min(2 * ch + (g >> 1), 8), dt = tap / 3, df = tap - 3 * dt;
+                const bf16x8 za = *reinterpret_cast<const bf16x8 *>(z1 + ((2 * tl + dt) * ZR + 2 * f + df) * ZC + 16 * blk + 8 * (g & 1));
+                acc = mma16(dwb[ch], za, acc);
+            }
+            const bf16x4 o = {(T)acc[0], (T)acc[1], (T)acc[2], (T)acc[3]};
+            const int col = cb + 16 * blk + 4 * g;
+            *reinterpret_cast<bf16x4 *>(xa + (col >> 6) * PANEL + p * 128 + ((((col & 63) >> 3) ^ (p & 7)) << 4) + ((col & 7) >> 2) * 8) = o;
+        }
+        stamp();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // Z1 tile free for the next pass; after the last pass the operand image is complete
+    }
+
+    // ---- pointwise conv.3 + ReLU: one step of the chain product, this wave's 32 output channels
+    const f32x4 bp0 = *reinterpret_cast<const f32x4 *>(bpw + 32 * wave + 4 * g), bp1 = *reinterpret_cast<const f32x4 *>(bpw + 32 * wave + 16 + 4 * g);
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { acc[i][0] = bp0; acc[i][1] = bp1; }
+#pragma unroll
+    for (int kk = 0; kk < KC1; ++kk) {
+        bf16x8 a[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = lds_frag_swz(xa + (kk >> 1) * PANEL + (16 * i + r16) * 128, kk & 1, g, swz, T());
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][j] = mma16(ring[2 * kk + j], a[i], acc[i][j]);
+    }
+    stamp();
+    unsigned char *tile = reinterpret_cast<unsigned char *>(z1);          // bf16 [96][OS]: the Z1 tile is dead
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = 16 * i + r16;
+            const bf16x4 o = {(T)fmaxf(acc[i][j][0], 0.f), (T)fmaxf(acc[i][j][1], 0.f), (T)fmaxf(acc[i][j][2], 0.f), (T)fmaxf(acc[i][j][3], 0.f)};
+            *reinterpret_cast<bf16x4 *>(tile + row * OS + (32 * wave + 16 * j + 4 * g) * 2) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stamp();
+    // rows (frame tl, f) of this line are consecutive rows of the (B*T*F, C) output: coalesced 16-byte stores
+    T *out = Z3 + ((size_t)b * Tn + t0) * F * C;
+    for (int id = tid; id < BMC * 32; id += 512) {
+        const int row = id >> 5, ch = id & 31;
+        if (t0 + row / F < Tn) copy16(out + (size_t)row * C + ch * 8, reinterpret_cast<const T *>(tile + row * OS + ch * 16));
+    }
+    stamp();
+}
+
+static inline bool frontend96_supported(int C, int F1, int F2, int H) { return C == 256 && F2 == 24 && F1 <= 2 * F2 && H <= 4 * F2; }
+
+template <typename TIn>
+static inline hipError_t launch_frontend96(hipStream_t s, const TIn *X, int N, int H, int W, int T1, int F1, int Tn, const bf16_t *w0f, const float *b0,
+                                           const bf16_t *dwf, const float *b2, const bf16_t *wpw, const float *bpw, bf16_t *Z3, unsigned long long *stamps = nullptr) {
+    const int FT = (F1 + 15) / 16, HS = 2 * 16 * FT + 4;
+    const size_t z1b = (size_t)9 * 50 * 72 * 2, tileb = (size_t)96 * (256 * 2 + 16);
+    const size_t lds = (size_t)4 * 96 * 128 + std::max(z1b, tileb) + (size_t)20 * HS * 2 + 10240;
+    auto kern = frontend96_kernel<TIn>;
+    hipError_t e = raise_lds_limit((const void *)kern, lds + 4096);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((Tn + 3) / 4, N), dim3(512), lds, s, X, H, W, T1, F1, Tn, w0f, b0, dwf, b2, wpw, bpw, Z3, HS, stamps);
+    return hipGetLastError();
+}

@@ -131,3 +131,28 @@ def test_weight_blob_export_import_roundtrip(case):
     assert torch.equal(la, lb)
     view = a.weight_blob()                       # zero-copy view of the library-owned blob
     assert view.dtype == torch.uint8 and view.numel() == a.blob_nbytes() and torch.equal(view, a.export_blob())
+
+
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('as_u8', [False, True])
+def test_frontend_conv_on_matrix_cores(as_u8, fused, monkeypatch):
+    """bf16 mode, 256 conv channels: the frontend convolutions run as MFMA products -- fused with the pointwise conv
+    (frontend.hip.h frontend96_kernel, the default) or as the stand-alone conv.0 + depthwise kernel (conv.hip.h
+    frontend_conv12_mfma_kernel, COCR_NO_FRONT96=1).  Stage outputs against the oracle's (fp32) on a width that leaves a
+    ragged last 4-frame group; tolerance = bf16 rounding of pixels, taps, Z1 and Z2."""
+    from conformer_ocr_amd import synth
+    if not fused:
+        monkeypatch.setenv('COCR_NO_FRONT96', '1')
+    hp = synth.hparams('cfg2', num_encoder_layers=1)
+    state = synth.make_state_dict(hp, seed=77, decoder_gain=8.0)
+    image, lens = synth.make_lines(3, hp.height, 346, seed=5)
+    eng, logits, out_lens = run_hip(hp, state, image, lens, 'bf16', debug=True, as_u8=as_u8)
+    N, T = image.shape[0], logits.shape[1]
+    _, _, otaps = oracle_taps(hp, state, image, lens)
+    worst = {}
+    for nm in (('front.z3',) if fused else ('front.z2', 'front.z3')):
+        ref = otaps[nm]
+        got = hip_tap(eng, nm, hp, N, T)
+        worst[nm] = float(np.abs(got - ref).max() / max(1e-6, np.abs(ref).max()))
+    _log(f'frontend_mfma_u8{int(as_u8)}_fused{int(fused)}', worst)
+    assert all(v <= 2e-2 for v in worst.values()), worst
