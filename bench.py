@@ -44,6 +44,7 @@ def kernel_table(hp, n, w, dtype):
     M = n * T
     ncls = hp.num_classes
     return {
+        'frontend_fused': ('mfma', 2.0 * n * (9 * C * T1 * out_len(hp.height, 1) + 9 * C * T * F) + 2.0 * n * T * F * C * C),
         'frontend_conv12': ('valu', 2.0 * n * (9 * C * T1 * out_len(hp.height, 1) + 9 * C * T * F)),
         'gemm_front_pw': ('mfma', 2.0 * n * T * F * C * C),
         'gemm_front_out': ('mfma', 2.0 * M * F * C * D),
@@ -72,8 +73,9 @@ def pmc_traffic(family):
     import csv
     import glob
     names = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12',
-             'chain_pw2_ffn_ffn_qkv': 'chain_kernel<0, 1, 1, 3>', 'chain_attn_out_glu': 'chain_kernel<0, 2, -1, -1>',
-             'chain_ffn_qkv': 'chain_kernel<1, 3, -1, -1>', 'chain_pw2_ffn': 'chain_kernel<0, 1, -1, -1>'}
+             'frontend_fused': 'frontend96_kernel',
+             'chain_pw2_ffn_ffn_qkv': 'chain96_kernel<31, 0, 1, 1, 3>', 'chain_attn_out_glu': 'chain96_kernel<0, 0, 2, -1, -1>',
+             'chain_ffn_qkv': 'chain96_kernel<0, 1, 3, -1, -1>', 'chain_pw2_ffn': 'chain96_kernel<31, 0, 1, -1, -1>'}
     if family not in names:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.csv')))

@@ -49,7 +49,7 @@ template <typename T, int DHP>   // DHP = padded head dim, multiple of 32
 __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
                                                                const T *__restrict__ ptab, const float *__restrict__ ub,
                                                                const float *__restrict__ vb, T *__restrict__ ctx,
-                                                               int Tn, int Tp, int heads, int dh, float scale) {
+                                                               int Tn, int Tp, int heads, int dh, float scale, unsigned long long *stamps) {
     constexpr int KC = DHP / 32;                      // k-chunks over the head dim
     constexpr int DT = DHP / 16;                      // 16-row tiles of O^T
     constexpr int SK = 20;                            // row stride (floats) of the shift tile: conflict-free write and skewed read
@@ -68,6 +68,16 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     const int i0b = blockIdx.x * 64, i0 = i0b + wave * 16;
     const int iq = min(i0 + il, Tn - 1);              // queries beyond T read row T-1 and store nothing
 
+#ifdef COCR_CHAIN_STAMPS_BUILD
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (stamps && blockIdx.x == 1 && blockIdx.y == 5 && tid == 0) stamps[nstamp] = __builtin_readcyclecounter();
+        ++nstamp;
+    };
+#else
+    auto stamp = [&]() {};
+#endif
+    stamp();
     const T *kbase = k + (size_t)bh * Tp * DHP;
     const T *vbase = v + (size_t)bh * Tp * DHP;
     const int prow = heads * DHP;
@@ -139,8 +149,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             for (int j = 0; j < 8; ++j) {
                 const int d = c * 32 + 8 * g + j;
                 const float x = to_f32(qq[c][j]);
-                qu[c][j] = d < dh ? from_f32<T>(x + u4[c][j >> 2][j & 3]) : (T)0.0f;
-                qv[c][j] = d < dh ? from_f32<T>(x + v4[c][j >> 2][j & 3]) : (T)0.0f;
+                qu[c][j] = d < dh ? from_f32<T>((x + u4[c][j >> 2][j & 3]) * scale) : (T)0.0f;      // 1/sqrt(d_head) folded into the query operands
+                qv[c][j] = d < dh ? from_f32<T>((x + v4[c][j >> 2][j & 3]) * scale) : (T)0.0f;
             }
     }
 
@@ -150,10 +160,13 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     float m_run = -INFINITY, l_run = 0.f;
     float *sk = skew + wave * 48 * SK;
 
+    stamp();
     for (int j0 = 0; j0 < Tn; j0 += 64) {
         __syncthreads();                       // every wave is done with the previous tile
+        stamp();
         store_tile();
         __syncthreads();
+        stamp();
         load_tile(j0 + 64 < Tn ? j0 + 64 : j0);   // in flight during the compute below (unconditional: the staging registers stay registers)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -181,43 +194,55 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             }
             // the shift tile is private to the wave: LDS operations of one wave execute in order
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bool tail = js + 32 > Tn;                      // uniform: only the last sub-tile has keys beyond T to mask
             float tmax = -INFINITY;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int jl = 16 * tt + 4 * g + r;
-                    float s = (sc[tt][r] + sk[(15 - il + jl) * SK + il]) * scale;
-                    s = (js + jl < Tn) ? s : -INFINITY;          // keys of the padded tail of the last tile
-                    sc[tt][r] = s;
-                    tmax = fmaxf(tmax, s);
+                    float sv = sc[tt][r] + sk[(15 - il + jl) * SK + il];
+                    if (tail) sv = (js + jl < Tn) ? sv : -INFINITY;
+                    sc[tt][r] = sv;
+                    tmax = fmaxf(tmax, sv);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next sub-tile overwrites the shift tile
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);               // finite: key js is valid
-            const float alpha = __expf(m_run - m_new);
-            m_run = m_new;
+            // Lazy rescaling: the running reference m_run is only raised when some query of the wave exceeds it by more than
+            // LAZY (softmax is invariant to the reference; exp(score - m_run) <= e^LAZY stays well inside fp32 / bf16 range), so
+            // the accumulators are not touched by the VALU in the common case.  The first sub-tile sets the reference.
+            constexpr float LAZY = 8.0f;
+            if (j0 == 0 && s2 == 0) {
+                m_run = tmax;                                     // finite: key 0 is valid
+            } else if (__builtin_amdgcn_ballot_w64(tmax > m_run + LAZY) != 0) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __expf(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+            }
             float psum = 0.f;
             frag_t pb;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(sc[tt][r] - m_new);
+                    const float p = __expf(sc[tt][r] - m_run);
                     psum += p;
                     pb[4 * tt + r] = from_f32<T>(p);
                 }
-            l_run = l_run * alpha + psum;
-            // ---- O^T = alpha O^T + V^T_sub . P^T
+            l_run += psum;
+            // ---- O^T += V^T_sub . P^T
 #pragma unroll
-            for (int d = 0; d < DT; ++d) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
-                o[d] = mma16(load_vt_frag(vs, RS, 32 * s2, d, il, g, T()), pb, o[d]);
-            }
+            for (int d = 0; d < DT; ++d) o[d] = mma16(load_vt_frag(vs, RS, 32 * s2, d, il, g, T()), pb, o[d]);
+            stamp();
         }
     }
+    stamp();
     // ---- normalise and store: lane holds head dims 16 d + 4g + r of query i0 + il
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);

@@ -124,10 +124,10 @@ struct cocr_model {
     std::vector<hipEvent_t> ev_pool;
 };
 
-static const char *FAMILIES[] = {"frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
+static const char *FAMILIES[] = {"frontend_fused", "frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
                                  "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "chain_ffn_qkv", "chain_attn_out_glu", "chain_pw2_ffn_ffn_qkv", "chain_pw2_ffn", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
                                  "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam"};
-enum { FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_CH_FIRST, FAM_CH_A, FAM_CH_B, FAM_CH_LAST, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
+enum { FAM_FRONT96, FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_CH_FIRST, FAM_CH_A, FAM_CH_B, FAM_CH_LAST, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
        FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_COUNT };
 
 static int out_len1(int l) { return l >= 1 ? (l - 1) / 2 + 1 : 0; }
@@ -236,7 +236,9 @@ extern "C" void cocr_destroy(cocr_model *m) {
         fprintf(stderr, "chain stamps (cycles since first):");
         for (int i = 1; i < 128 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[0]);
         fprintf(stderr, "\nfrontend stamps:");
-        for (int i = 129; i < 256 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[128]);
+        for (int i = 129; i < 192 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[128]);
+        fprintf(stderr, "\nattention stamps:");
+        for (int i = 193; i < 256 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[192]);
         fprintf(stderr, "\n");
         (void)hipHostFree(m->stamps);
     }
@@ -658,12 +660,12 @@ extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, d
 
 template <typename T, int DHP>
 static hipError_t launch_attention(hipStream_t s, dim3 grid, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
-                                   const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale) {
+                                   const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, unsigned long long *stamps = nullptr) {
     const size_t lds = attention_lds_bytes<T, DHP>();
     auto kern = relpos_attention_kernel<T, DHP>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh, scale);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh, scale, stamps);
     return hipGetLastError();
 }
 
@@ -684,7 +686,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     bool front_fused = false;
     if constexpr (sizeof(T) == 2) {
         if (uses_frontend96(m)) {                        // conv.0 + ReLU + depthwise conv.2 + pointwise conv.3 + ReLU in one kernel (frontend.hip.h)
-            ProfScope ps(m, s, FAM_CONV12);
+            ProfScope ps(m, s, FAM_FRONT96);
             const size_t n0 = (size_t)(C / 16) * 64 * 4;
             GEMM_TRY(launch_frontend96<TIn>(s, lines, N, H, W, T1, F1, T2, m->fpack, F32(P.b0), m->fpack + n0, F32(P.stages[0].dw_b),
                                             (const bf16_t *)(m->packed + P.stages[0].pw_w), F32(P.stages[0].pw_b), (bf16_t *)zb, m->stamps ? m->stamps + 128 : nullptr));
@@ -840,7 +842,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 {
                     ProfScope ps(m, s, FAM_ATTN);
                     dim3 grid(ceil_div(Tn, 64), N * heads);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
                     if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
                 }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *xa = smem;                                             // 96 x 256 bf16 operand image (Z2)
     T *z1 = reinterpret_cast<T *>(smem + IMG);                            // [NA][ZR][ZC]; later the bf16 output tile [96][OS]
-    T *xs = z1 + NA * ZR * ZC;                                            // [NCOL][HS] transposed line tile: row rr <-> image row rr - 1
+    T *xs = z1 + (NA * ZR + 1) * ZC;                                      // (one dump row behind the Z1 tile) [NCOL][HS] transposed line tile: row rr <-> image row rr - 1
     unsigned char *prm = reinterpret_cast<unsigned char *>(xs + NCOL * HS);   // conv.0 A-fragments (8 KiB), b0 (1 KiB), b2 (1 KiB); 16-byte aligned (HS % 4 == 0)
     const T *w0s = reinterpret_cast<const T *>(prm);
     const float *b0s = reinterpret_cast<const float *>(prm + 8192), *b2s = b0s + 256;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         pf[u] = __builtin_bit_cast(s16x4, (u32x2){*reinterpret_cast<const unsigned *>(px), *reinterpret_cast<const unsigned *>(px + 2)});
         valid[u] = t1 >= 0 && t1 < T1 && f1 < F1;
-        zoff[u] = (wave + 8 * u < ntile && f1 + 1 < ZR) ? (a * ZR + f1 + 1) * ZC : -1;
+        zoff[u] = (wave + 8 * u < ntile && f1 + 1 < ZR) ? (a * ZR + f1 + 1) * ZC : NA * ZR * ZC;      // else: the dump row behind the tile
     }
     // depthwise fragments of (pass, blk): one pass ahead in registers
     bf16x8 dwn[5];
@@ -151,16 +151,22 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
             bias0[nt] = *reinterpret_cast<const f32x4 *>(b0s + cb + 16 * nt + 4 * g);
         }
         // ---- conv.0 + ReLU -> Z1 tile
+        f32x4 c0[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) c0[u][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[nt], pf[u], bias0[nt], 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[nt], pf[u], bias0[nt], 0, 0, 0);
-                const bf16x4 o = {(T)fmaxf(acc[0], 0.0f), (T)fmaxf(acc[1], 0.0f), (T)fmaxf(acc[2], 0.0f), (T)fmaxf(acc[3], 0.0f)};
+                const f32x4 a = c0[u][nt];
+                const bf16x4 o = {(T)__builtin_amdgcn_fmed3f(a[0], 0.0f, INFINITY), (T)__builtin_amdgcn_fmed3f(a[1], 0.0f, INFINITY),
+                                  (T)__builtin_amdgcn_fmed3f(a[2], 0.0f, INFINITY), (T)__builtin_amdgcn_fmed3f(a[3], 0.0f, INFINITY)};      // ReLU
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 ob = __builtin_bit_cast(u32x2, o);
                 if (!valid[u]) ob = (u32x2){0u, 0u};                  // outside Z1: the depthwise conv's zero padding
-                if (zoff[u] >= 0) *reinterpret_cast<u32x2 *>(z1 + zoff[u] + 16 * nt + 4 * g) = ob;
+                *reinterpret_cast<u32x2 *>(z1 + zoff[u] + 16 * nt + 4 * g) = ob;       // (tiles beyond the last: a dump row)
             }
         stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -229,7 +235,7 @@ template <typename TIn>
 static inline hipError_t launch_frontend96(hipStream_t s, const TIn *X, int N, int H, int W, int T1, int F1, int Tn, const bf16_t *w0f, const float *b0,
                                            const bf16_t *dwf, const float *b2, const bf16_t *wpw, const float *bpw, bf16_t *Z3, unsigned long long *stamps = nullptr) {
     const int FT = (F1 + 15) / 16, HS = 2 * 16 * FT + 4;
-    const size_t z1b = (size_t)9 * 50 * 72 * 2, tileb = (size_t)96 * (256 * 2 + 16);
+    const size_t z1b = (size_t)(9 * 50 + 1) * 72 * 2, tileb = (size_t)96 * (256 * 2 + 16);
     const size_t lds = (size_t)4 * 96 * 128 + std::max(z1b, tileb) + (size_t)20 * HS * 2 + 10240;
     auto kern = frontend96_kernel<TIn>;
     hipError_t e = raise_lds_limit((const void *)kern, lds + 4096);
