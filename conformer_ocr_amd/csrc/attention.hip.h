@@ -120,7 +120,29 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     // B operands: (q + u) and (q + v) of this lane's query, per k-chunk; padded dims stay zero.  All loads (q fragments
     // and the 8 consecutive bias values of each) are issued before the first use: one round trip, not one per element.
     frag_t qu[KC], qv[KC];
-    {
+    if (dh == DHP) {
+        // common case (d_head a multiple of 32): no padded dims -- 16-byte loads only, no per-element selects
+        const T *qrow = q + ((size_t)bh * Tp + iq) * DHP;
+        frag_t qq[KC];
+        f32x4 u4[KC][2], v4[KC][2];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            qq[c] = load_frag(qrow + c * 32 + 8 * g);
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                u4[c][hlf] = *reinterpret_cast<const f32x4 *>(ub + hh * DHP + c * 32 + 8 * g + 4 * hlf);
+                v4[c][hlf] = *reinterpret_cast<const f32x4 *>(vb + hh * DHP + c * 32 + 8 * g + 4 * hlf);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = to_f32(qq[c][j]);
+                qu[c][j] = from_f32<T>((x + u4[c][j >> 2][j & 3]) * scale);      // 1/sqrt(d_head) folded into the query operands
+                qv[c][j] = from_f32<T>((x + v4[c][j >> 2][j & 3]) * scale);
+            }
+    } else {
         const T *qrow = q + ((size_t)bh * Tp + iq) * DHP;
         frag_t qq[KC];
         f32x4 u4[KC][2], v4[KC][2];
