@@ -84,6 +84,9 @@ int cocr_finalize(cocr_model *m, int compute_dtype);
  * without filling it, hands (ptr, bytes) to its collective library (RCCL broadcast from the rank
  * that ran cocr_finalize), and is then ready.  The blob layout depends only on (hparams, dtype). */
 int cocr_finalize_empty(cocr_model *m, int compute_dtype);
+/* Kernel-specific re-layouts of some matrices (MFMA-fragment order) are DERIVED from the blob on the first forward after
+ * cocr_finalize, cocr_blob_import or a call of cocr_weight_blob: a caller that writes through the pointer later must call
+ * cocr_weight_blob again (or use cocr_blob_import) before the next forward, or those copies stay stale. */
 int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes);
 /* The same through a caller-owned device buffer of exactly `bytes` = blob size (stream-ordered device-to-device copies):
  * export on the root, broadcast the caller's buffer, import on the other ranks. */
