@@ -112,6 +112,7 @@ struct cocr_model {
     std::vector<GraphEntry> graphs, graph_seen;
     bool debug = false;
     unsigned long long *stamps = nullptr;   // COCR_CHAIN_STAMPS=1 (dev): host-visible cycle stamps of one chain launch, printed at destroy
+    bool beam_ref = false;       // COCR_BEAM_REF=1: the exhaustive beam kernel (all beam x C candidates per frame) also for <= 256 classes
     bool no_front96 = false;     // COCR_NO_FRONT96=1: frontend conv stages as separate kernels (A/B)
     bool no_conv_mfma = false;   // COCR_NO_CONV_MFMA=1: the all-VALU fp32 frontend conv kernel also in bf16 mode (A/B)
     bool no_dw_fuse = false;     // COCR_NO_DW_FUSE=1: depthwise conv as its own launch (A/B)
@@ -170,6 +171,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_FRONT96"); m->no_front96 = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_BEAM_REF"); m->beam_ref = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_STAMPS"); if (e && e[0] == '1') { (void)hipHostMalloc((void **)&m->stamps, 256 * 8); memset(m->stamps, 0, 256 * 8); } }
     int f = hp->height;
     for (int i = 0; i < snum; ++i) { f = out_len1(f); m->feats.push_back(f); }
@@ -237,8 +239,10 @@ extern "C" void cocr_destroy(cocr_model *m) {
         for (int i = 1; i < 128 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[0]);
         fprintf(stderr, "\nfrontend stamps:");
         for (int i = 129; i < 192 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[128]);
+        fprintf(stderr, "\nbeam phase cycles (setup, folds, candidates, selection, update):");
+        for (int i = 240; i < 245 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i]);
         fprintf(stderr, "\nattention stamps:");
-        for (int i = 193; i < 256 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[192]);
+        for (int i = 193; i < 240 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[192]);
         fprintf(stderr, "\n");
         (void)hipHostFree(m->stamps);
     }
@@ -1074,22 +1078,33 @@ extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, i
     if (N < 1 || T < 1 || ncls < 2 || max_per_line < 1) return fail(COCR_EINVAL, "empty problem");
     if (beam < 1 || beam > COCR_BEAM_MAX) return fail(COCR_EINVAL, "beam must be in 1..%d", COCR_BEAM_MAX);
     if (ncls > 65535) return fail(COCR_EUNSUPPORTED, "more than 65535 classes");
-    const size_t lds = ((size_t)ncls + (size_t)beam * ncls) * 4 + COCR_BEAM_MAX * (11 * 4 + 2 * 8) + 64;
-    if (lds > 150 * 1024) return fail(COCR_EUNSUPPORTED, "beam x classes too large for the LDS candidate table");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     int rc = upload_lens(m, out_lens, N, s);
     if (rc) return rc;
-    const size_t need = (size_t)N * T * (COCR_BEAM_MAX + 1);
+    const bool fast = ncls <= 256 && !m->beam_ref;            // ctc_beam2_kernel: frames ranked in parallel, beam x (beam + 1) candidates per frame
+    const size_t per_frame = (size_t)COCR_BEAM_MAX + 1 + (fast ? (size_t)ncls + COCR_BEAM_KMAX : 0);      // 4-byte words of scratch per (line, frame)
+    const size_t need = (size_t)N * T * per_frame;
     if (need > m->beam_cap) {
         if (m->beam_bp) (void)hipFree(m->beam_bp);
         HIP_TRY(hipMalloc((void **)&m->beam_bp, need * 4));
         m->beam_cap = need;
     }
-    HIP_TRY(raise_lds_limit((const void *)ctc_beam_kernel, lds));
+    int32_t *bp = m->beam_bp;
+    float *logz = reinterpret_cast<float *>(bp + (size_t)N * T * COCR_BEAM_MAX);
     ProfScope ps(m, s, FAM_BEAM);
-    hipLaunchKernelGGL(ctc_beam_kernel, dim3(N), dim3(64), lds, s, logits, T, ncls, m->d_lens, beam, labels, starts, ends, conf, counts,
-                       max_per_line, m->beam_bp, reinterpret_cast<float *>(m->beam_bp + (size_t)N * T * COCR_BEAM_MAX));
+    if (fast) {
+        float *lp_all = logz + (size_t)N * T;
+        int32_t *topc = reinterpret_cast<int32_t *>(lp_all + (size_t)N * T * ncls);
+        hipLaunchKernelGGL(ctc_beam2_kernel, dim3(N), dim3(256), 0, s, logits, T, ncls, m->d_lens, beam, labels, starts, ends, conf, counts, max_per_line,
+                           lp_all, topc, bp, logz, m->stamps ? m->stamps + 240 : nullptr);
+    } else {
+        const size_t lds = ((size_t)ncls + (size_t)beam * ncls) * 4 + COCR_BEAM_MAX * (11 * 4 + 2 * 8) + 64;
+        if (lds > 150 * 1024) return fail(COCR_EUNSUPPORTED, "beam x classes too large for the LDS candidate table");
+        HIP_TRY(raise_lds_limit((const void *)ctc_beam_kernel, lds));
+        hipLaunchKernelGGL(ctc_beam_kernel, dim3(N), dim3(64), lds, s, logits, T, ncls, m->d_lens, beam, labels, starts, ends, conf, counts,
+                           max_per_line, bp, logz);
+    }
     LAUNCH_CHECK();
     return COCR_OK;
 }

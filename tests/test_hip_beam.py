@@ -68,3 +68,25 @@ def test_beam_zero_length_and_model_attribute(case):
     for n in range(image.shape[0]):
         want = ref_beam(g['logits'][n, :int(g['out_lens'][n])].T, 16)
         assert [x[0] for x in recs[n]] == [x[0] for x in want]
+
+
+@pytest.mark.parametrize('C,T,beam,scale', [(128, 300, 16, 2.5), (128, 300, 16, 0.3), (200, 120, 32, 1.5), (17, 90, 16, 1.0), (3, 50, 8, 1.0)])
+def test_beam_pruned_equals_exhaustive(C, T, beam, scale, monkeypatch):
+    """cocr_ctc_beam ranks beam x (beam + 1) candidates per frame (ctc_beam2_kernel); COCR_BEAM_REF=1 selects the kernel that
+    ranks all beam x C of them.  Every output field must agree exactly (same arithmetic, same tie rules), on peaked and on
+    nearly flat logits (many near-ties), full-length and ragged lines."""
+    from conformer_ocr_amd.engine import HipRecognizer
+    from conformer_ocr_amd.spec import HParams
+    hp = HParams(num_classes=2, height=16, encoder_dim=16, num_encoder_layers=1, num_attention_heads=1, conv_kernel_size=3,
+                 subsampling_conv_channels=8)
+    g = np.random.default_rng(C * 7919 + T)
+    N = 6
+    logits = (g.normal(size=(N, T, C)) * scale).astype(np.float32)
+    logits[:, :, 0] += 1.0
+    logits[1, :, 1:] = np.round(logits[1, :, 1:] * 2) / 2          # exact ties between classes
+    lens = [T, T - 1, T // 2, 1, T, 7]
+    x = torch.from_numpy(logits).cuda()
+    fast = HipRecognizer(hp, torch.device('cuda', 0), 'fp32').ctc_beam(x, lens, beam)
+    monkeypatch.setenv('COCR_BEAM_REF', '1')
+    ref = HipRecognizer(hp, torch.device('cuda', 0), 'fp32').ctc_beam(x, lens, beam)
+    assert fast == ref
