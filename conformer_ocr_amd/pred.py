@@ -234,3 +234,44 @@ def save_safetensors(net: PytorchRecognitionModel, path, extra_metadata: Optiona
             ti = tarfile.TarInfo(name)
             ti.size = len(data)
             tf.addfile(ti, io.BytesIO(data))
+
+
+def average_checkpoints(paths, num_checkpoints: Optional[int] = None) -> Dict:
+    """The reference's `avg_ckpts` (cli/train.py:37-98): element-wise mean of the `state_dict`s of the last `num_checkpoints`
+    checkpoints of `paths` (sorted by name like the reference's glob); everything else is taken from the first of them.
+    Floating tensors: sum, then in-place division; integer tensors (BatchNorm `num_batches_tracked`): floor division;
+    half tensors are summed in float32; a checkpoint whose key list differs raises KeyError.  Returns the averaged checkpoint
+    dict (`torch.save` it, or hand `['state_dict']` to `load_state_dict`)."""
+    import collections
+    ckpts = sorted(str(p) for p in paths)
+    if num_checkpoints is not None:
+        if num_checkpoints < 2:
+            raise ValueError('at least 2 checkpoints are averaged')
+        if len(ckpts) < num_checkpoints:
+            raise ValueError(f'Less checkpoints found than requested for averaging ({len(ckpts)} < {num_checkpoints})')
+        ckpts = ckpts[-num_checkpoints:]
+    params, keys, new_state = collections.OrderedDict(), None, None
+    for fpath in ckpts:
+        state = torch.load(fpath, map_location='cpu', weights_only=True)
+        if new_state is None:
+            new_state = state
+        sd = state['state_dict']
+        if keys is None:
+            keys = list(sd.keys())
+        elif keys != list(sd.keys()):
+            raise KeyError(f'For checkpoint {fpath}, expected list of params: {keys}, but found: {list(sd.keys())}')
+        for k in keys:
+            p = sd[k]
+            if p.dtype == torch.float16:
+                p = p.float()
+            if k not in params:
+                params[k] = p.clone()
+            else:
+                params[k] += p
+    for k, v in params.items():
+        if v.is_floating_point():
+            v.div_(len(ckpts))
+        else:
+            v //= len(ckpts)
+    new_state['state_dict'] = params
+    return new_state

@@ -153,3 +153,30 @@ def test_synthetic_generators_are_deterministic():
     img, lens = synth.make_lines(3, 16, 64, seed=2, widths=[64, 37, 50])
     assert img.shape == (3, 1, 16, 64) and img.dtype == np.float32 and (img[1, :, :, 37:] == 0).all()
     np.testing.assert_array_equal(synth.lines_u8(img).astype(np.float32) / np.float32(255.0), img)
+
+
+def test_average_checkpoints_like_the_reference(tmp_path):
+    """cli/train.py:37-98: mean of the last n checkpoints' state dicts; ints floor-divided; key mismatch raises."""
+    import torch
+    from conformer_ocr_amd.pred import average_checkpoints
+    g = torch.Generator().manual_seed(3)
+    paths = []
+    for i in range(4):
+        sd = {'nn.a.weight': torch.randn(3, 2, generator=g), 'nn.bn.num_batches_tracked': torch.tensor(10 * i + 3),
+              'nn.h': torch.randn(4, generator=g).half()}
+        f = tmp_path / f'checkpoint_{i:02d}-0.1.ckpt'
+        torch.save({'state_dict': sd, 'hyper_parameters': {'height': 96, 'epoch': i}}, f)
+        paths.append(f)
+    avg = average_checkpoints(paths, 3)
+    loaded = [torch.load(p, weights_only=True)['state_dict'] for p in paths[-3:]]
+    want = sum(s['nn.a.weight'] for s in loaded) / 3
+    assert torch.allclose(avg['state_dict']['nn.a.weight'], want)
+    assert int(avg['state_dict']['nn.bn.num_batches_tracked']) == (13 + 23 + 33) // 3
+    assert avg['state_dict']['nn.h'].dtype == torch.float32
+    assert avg['hyper_parameters']['epoch'] == 1            # everything else from the first averaged checkpoint
+    with pytest.raises(ValueError):
+        average_checkpoints(paths, 9)
+    bad = tmp_path / 'checkpoint_99-0.1.ckpt'
+    torch.save({'state_dict': {'other': torch.zeros(1)}}, bad)
+    with pytest.raises(KeyError):
+        average_checkpoints(paths + [bad], 2)
