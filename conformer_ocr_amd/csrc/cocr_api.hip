@@ -26,6 +26,7 @@
 #include "chain.hip.h"
 #include "frontend.hip.h"
 #include "norm.hip.h"
+#include "preproc.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -98,6 +99,8 @@ struct cocr_model {
     void *xn = nullptr, *hid = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *glu = nullptr, *dwo = nullptr;
     size_t qkv_bytes = 0;
     int vtN = -1, vtT = -1;    // shape the q/k/vt buffers were last zeroed for
+    unsigned char *pre_buf = nullptr;      // line pre-processing: descriptors, tap tables, intermediates
+    size_t pre_cap = 0;
     int32_t *d_lens = nullptr;
     int32_t *ctc_lab = nullptr;
     float *ctc_val = nullptr;
@@ -233,6 +236,7 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->blob) (void)hipFree(m->blob);
     if (m->packed) (void)hipFree(m->packed);
     if (m->fpack) (void)hipFree(m->fpack);
+    if (m->pre_buf) (void)hipFree(m->pre_buf);
     if (m->stamps) {
         (void)hipDeviceSynchronize();
         fprintf(stderr, "chain stamps (cycles since first):");
@@ -1105,6 +1109,55 @@ extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, i
         hipLaunchKernelGGL(ctc_beam_kernel, dim3(N), dim3(64), lds, s, logits, T, ncls, m->d_lens, beam, labels, starts, ends, conf, counts,
                            max_per_line, bp, logz);
     }
+    LAUNCH_CHECK();
+    return COCR_OK;
+}
+
+// ------------------------------------------------------------------------------------ line pre-processing (preproc.hip.h)
+extern "C" int32_t cocr_preproc_width(int32_t h, int32_t w, int32_t out_h, int32_t pad) {
+    if (h < 1 || w < 1 || out_h < 1 || pad < 0) return -1;
+    return pre_scaled_width(h, w, out_h) + 2 * pad;
+}
+
+extern "C" int cocr_preproc_lines(cocr_model *m, const uint8_t *pixels, const int64_t *offsets, const int32_t *heights, const int32_t *widths,
+                                  const int32_t *channels, int N, int out_h, int pad, int out_w, uint8_t *out, int32_t *out_widths, void *stream) {
+    if (!m || !pixels || !offsets || !heights || !widths || !out || !out_widths) return fail(COCR_EINVAL, "null argument");
+    if (N < 1 || out_h < 1 || pad < 0 || out_w < 1) return fail(COCR_EINVAL, "empty problem");
+    std::vector<PreLine> lines((size_t)N);
+    std::vector<int> tab;
+    size_t tmp_bytes = 0;
+    int max_h = 0, max_ow = 0;
+    for (int i = 0; i < N; ++i) {
+        const int h = heights[i], w = widths[i], cpp = channels ? channels[i] : 1;
+        if (h < 1 || w < 1 || (cpp != 1 && cpp != 3)) return fail(COCR_EINVAL, "line %d: %d x %d pixels, %d channels", i, h, w, cpp);
+        PreLine &L = lines[(size_t)i];
+        L.in_off = offsets[i]; L.h = h; L.w = w; L.cpp = cpp; L.ow = pre_scaled_width(h, w, out_h);
+        if (L.ow + 2 * pad > out_w) return fail(COCR_EINVAL, "size mismatch: line %d is %d px wide after scaling and padding, the batch %d", i, L.ow + 2 * pad, out_w);
+        pre_coeffs(w, L.ow, tab, &L.hb, &L.hk, &L.hks);
+        pre_coeffs(h, out_h, tab, &L.vb, &L.vk, &L.vks);
+        L.tmp_off = (long long)tmp_bytes;
+        tmp_bytes += (size_t)h * L.ow;
+        out_widths[i] = L.ow + 2 * pad;
+        max_h = std::max(max_h, h); max_ow = std::max(max_ow, L.ow);
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lines_b = round_up((int)(lines.size() * sizeof(PreLine)), 256), tab_b = (size_t)round_up((int)(tab.size() * 4), 256);
+    const size_t need = lines_b + tab_b + tmp_bytes;
+    if (need > m->pre_cap) {
+        HIP_TRY(hipStreamSynchronize(s));                  // an earlier call on this stream may still read the old buffer
+        if (m->pre_buf) (void)hipFree(m->pre_buf);
+        HIP_TRY(hipMalloc((void **)&m->pre_buf, need + need / 4));
+        m->pre_cap = need + need / 4;
+    }
+    PreLine *d_lines = reinterpret_cast<PreLine *>(m->pre_buf);
+    int *d_tab = reinterpret_cast<int *>(m->pre_buf + lines_b);
+    unsigned char *d_tmp = m->pre_buf + lines_b + tab_b;
+    HIP_TRY(hipMemcpyAsync(d_lines, lines.data(), lines.size() * sizeof(PreLine), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                      // the host tables go out of scope; also orders reuse of pre_buf by the next call
+    hipLaunchKernelGGL(preproc_h_kernel, dim3(ceil_div(max_ow, 256), max_h, N), dim3(256), 0, s, pixels, d_lines, d_tab, d_tmp);
+    hipLaunchKernelGGL(preproc_v_kernel, dim3(ceil_div(out_w, 256), out_h, N), dim3(256), 0, s, d_tmp, d_lines, d_tab, out, out_h, out_w, pad);
     LAUNCH_CHECK();
     return COCR_OK;
 }

@@ -200,6 +200,41 @@ class HipRecognizer:
     def ctc_beam(self, logits: torch.Tensor, out_lens, beam: int = 16) -> List[List[Tuple[int, int, int, float]]]:
         return self._decode(self.lib.cocr_ctc_beam, logits, out_lens, extra=(int(beam),))
 
+    # ---- line pre-processing (include/cocr.h: cocr_preproc_lines) --------------------------------------
+    def preprocess(self, lines: Sequence[np.ndarray], height: Optional[int] = None, pad: int = 16, width: int = 0,
+                   bucket_edge: int = 0) -> Tuple[torch.Tensor, np.ndarray]:
+        """Raw 8-bit line crops ((H, W) grayscale or (H, W, 3) RGB numpy arrays, any height) -> the (N, height, Wb) uint8 device
+        batch `forward` ingests, and the lines' widths after scaling and padding (the batch's `seq_lens`).  Grayscale, Pillow
+        LANCZOS scaling to `height` (default: the model's), `pad` zero columns left and right, right-zero-filled to Wb = `width`,
+        or the widest line rounded up to a multiple of `bucket_edge`, or the widest line."""
+        height = int(height or self.hp.height)
+        n = len(lines)
+        if n < 1:
+            raise ValueError('empty batch')
+        hs = np.array([x.shape[0] for x in lines], dtype=np.int32)
+        ws = np.array([x.shape[1] for x in lines], dtype=np.int32)
+        ch = np.array([1 if x.ndim == 2 else x.shape[2] for x in lines], dtype=np.int32)
+        for x in lines:
+            if x.dtype != np.uint8 or x.ndim not in (2, 3):
+                raise ValueError('line crops are (H, W) or (H, W, 3) uint8 arrays')
+        sizes = hs.astype(np.int64) * ws * ch
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        flat = np.concatenate([np.ascontiguousarray(x).reshape(-1) for x in lines])
+        wl = [int(self.lib.cocr_preproc_width(int(h), int(w), height, int(pad))) for h, w in zip(hs, ws)]
+        wb = int(width) if width else max(wl)
+        if not width and bucket_edge:
+            wb = -(-wb // int(bucket_edge)) * int(bucket_edge)
+        px = torch.from_numpy(flat).to(self.device)
+        out = torch.empty((n, height, wb), dtype=torch.uint8, device=self.device)
+        lens = np.zeros(n, dtype=np.int32)
+        _lib.check(self.lib.cocr_preproc_lines(self._h, C.c_void_p(px.data_ptr()), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                               hs.ctypes.data_as(C.POINTER(C.c_int32)), ws.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               ch.ctypes.data_as(C.POINTER(C.c_int32)), n, height, int(pad), wb,
+                                               C.c_void_p(out.data_ptr()), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               _stream_ptr(self.device)))
+        self._keep = px            # the kernels read it asynchronously on the current stream
+        return out, lens
+
     # ---- test / measurement hooks ---------------------------------------------------------------
     def set_debug(self, on: bool) -> None:
         _lib.check(self.lib.cocr_set_debug(self._h, int(on)))

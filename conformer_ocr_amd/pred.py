@@ -151,6 +151,15 @@ class PytorchRecognitionModel(nn.Module):
             probits, out_lens = eng.forward(line.squeeze(1), torch.as_tensor(lens).cpu().numpy())
         return probits, torch.from_numpy(out_lens)
 
+    def transform_lines(self, crops, pad: int = 16, bucket_edge: int = 0, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The step kraken's `ImageInputTransforms(1, height, 0, 1, (pad, 0))` performs in the reference's data pipeline
+        (dataset.py:89, cli/test.py:156), on the GPU: raw 8-bit line crops ((H, W) or (H, W, 3) numpy arrays of any height) ->
+        a `(N, 1, height, W)` uint8 line batch (pixel / 255 = the [0, 1] floats `forward` expects; it ingests uint8 directly)
+        and the `seq_lens` (scaled width + 2 pad).  W = the widest line, rounded up to a multiple of `bucket_edge` if given."""
+        eng = self.engine(device)
+        batch, lens = eng.preprocess(list(crops), height=self.height, pad=pad, bucket_edge=bucket_edge)
+        return batch.unsqueeze(1), torch.from_numpy(lens)
+
     def _label_records(self, line: torch.Tensor, lens: torch.Tensor) -> List[List[Tuple[int, int, int, float]]]:
         o, olens = self.forward(line, lens)
         if isinstance(self.ctc_decoder, GreedyDecoder):

@@ -126,6 +126,19 @@ int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, int ncls, co
                   int32_t *labels, int32_t *starts, int32_t *ends, float *conf, int32_t *counts,
                   int max_per_line, int beam, void *stream);
 
+/* Line pre-processing in front of the path -- the step the reference delegates to kraken's
+ * ImageInputTransforms(1, 96, 0, 1, (16, 0), valid_norm=False) (reference dataset.py:89, cli/test.py:156): grayscale, scale to
+ * height `out_h` keeping the aspect ratio (Pillow's 8-bit LANCZOS resampler, bit for bit), `pad` zero columns left and right,
+ * right-zero-filled to the batch width.  Input: N raw 8-bit line crops packed in one DEVICE buffer `pixels` (line i starts at
+ * byte offsets[i], heights[i] rows of widths[i] pixels of channels[i] = 1 (L) or 3 (RGB, converted like Pillow) bytes;
+ * channels == NULL: all 1).  Output: `out` (N, out_h, out_w) uint8 on the device -- the COCR_U8 line batch of cocr_forward
+ * (pixel / 255 are the reference's [0, 1] floats) -- and out_widths[i] (HOST) = scaled width + 2 pad, the batch's `seq_lens`.
+ * Errors: COCR_EINVAL if a scaled line does not fit out_w.  Synchronises `stream` once (tap tables are built on the host).
+ * cocr_preproc_width: the width line (h, w) will have, for choosing out_w / bucketing before the call. */
+int32_t cocr_preproc_width(int32_t h, int32_t w, int32_t out_h, int32_t pad);
+int cocr_preproc_lines(cocr_model *m, const uint8_t *pixels, const int64_t *offsets, const int32_t *heights, const int32_t *widths,
+                       const int32_t *channels, int N, int out_h, int pad, int out_w, uint8_t *out, int32_t *out_widths, void *stream);
+
 /* Launch-overhead control: with graph replay on, the second cocr_forward call with identical (lines, logits, N, W,
  * dtype, stream) captures its ~120 kernel launches into a hipGraph and later identical calls replay it.  The caller
  * must then keep `lines` / `logits` at the same addresses (contents may change).  Off by default. */
