@@ -74,14 +74,42 @@ def collate(lines: Sequence[np.ndarray], idx: Sequence[int], width: int) -> Tupl
 
 
 def recognize(net, lines: Sequence[np.ndarray], batch_size: int = 32, edge: int = 200, rank: int = 0, world: int = 1,
-              device: str = 'cuda:0') -> Dict[int, str]:
-    """Strings for this rank's share of `lines` (H x w float arrays in [0,1]); keys are line indices."""
+              device: str = 'cuda:0', pipelined: bool = True) -> Dict[int, str]:
+    """Strings for this rank's share of `lines` (H x w float arrays in [0,1]); keys are line indices.
+
+    pipelined: batch k+1 is collated, copied host->device (pinned staging buffer, side stream) and enqueued while batch k is
+    computed; batch k's label records are read back while batch k+1 runs (the reference's loop, cli/test.py:185-212, is
+    serial: copy, forward, decode, next).  Same strings either way."""
     batches = make_batches([l.shape[1] for l in lines], batch_size, edge)
     out: Dict[int, str] = {}
+    dev = torch.device(device)
+    if not pipelined:
+        for b in shard_batches(len(batches), rank, world):
+            width, idx = batches[b]
+            im, lens = collate(lines, idx, width)
+            for i, s in zip(idx, net.predict_string(im.to(dev), lens)):
+                out[i] = s
+        return out
+    copy_stream = torch.cuda.Stream(dev)
+    pending = None
     for b in shard_batches(len(batches), rank, world):
         width, idx = batches[b]
         im, lens = collate(lines, idx, width)
-        for i, s in zip(idx, net.predict_string(im.to(device, non_blocking=True), lens)):
+        staged = im.pin_memory()
+        with torch.cuda.stream(copy_stream):
+            d_im = staged.to(dev, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record(copy_stream)
+        main = torch.cuda.current_stream(dev)
+        main.wait_event(arrived)
+        handle = net.predict_string_async(d_im, lens)
+        d_im.record_stream(main)
+        if pending is not None:
+            for i, s in zip(pending[0], net.collect_strings(pending[1])):
+                out[i] = s
+        pending = (idx, handle, staged)
+    if pending is not None:
+        for i, s in zip(pending[0], net.collect_strings(pending[1])):
             out[i] = s
     return out
 

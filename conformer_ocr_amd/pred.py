@@ -185,6 +185,24 @@ class PytorchRecognitionModel(nn.Module):
         """
         return [''.join(x[0] for x in self.codec.decode(locs)) for locs in self._label_records(line, lens)]
 
+    def predict_string_async(self, line: torch.Tensor, lens: torch.Tensor):
+        """`predict_string` split in two for pipelined callers (conformer_ocr_amd/evaluate.py): enqueues forward, CTC decode and
+        the read-back of the label records on the current stream and returns a handle; `collect_strings(handle)` waits for
+        that batch only -- the next batch's upload and forward can be in flight meanwhile."""
+        o, olens = self.forward(line, lens)
+        eng = self._engine
+        if isinstance(self.ctc_decoder, GreedyDecoder):
+            return ('device', eng.ctc_greedy_async(o, olens.numpy()))
+        if isinstance(self.ctc_decoder, BeamDecoder):
+            return ('device', eng._decode_async(eng.lib.cocr_ctc_beam, o, olens.numpy(), extra=(int(self.ctc_decoder.beam_size),)))
+        o = o.transpose(1, 2).cpu().float().numpy()           # a user-supplied decoder: the reference's own host loop
+        return ('host', [self.ctc_decoder(seq[:, :int(seq_len)]) for seq, seq_len in zip(o, olens)])
+
+    def collect_strings(self, handle) -> List[str]:
+        kind, h = handle
+        records = self._engine.collect(h) if kind == 'device' else h
+        return [''.join(x[0] for x in self.codec.decode(locs)) for locs in records]
+
     def predict_labels(self, line: torch.tensor, lens: torch.Tensor = None) -> List[List[Tuple[int, int, int, float]]]:
         """
         Forward pass on a (N, C, H, W) batch; returns per line a list of tuples

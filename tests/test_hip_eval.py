@@ -37,3 +37,21 @@ def test_bucketed_evaluation_mixed_widths(case):
     b = recognize(_net(hp, state, 'fp32'), lines, batch_size=8, rank=1, world=2)
     assert set(a) | set(b) == set(range(24)) and not (set(a) & set(b))
     assert all(ref[i] == s for i, s in {**a, **b}.items())
+
+
+def test_pipelined_loop_equals_serial_loop(case):
+    """recognize(pipelined=True) overlaps upload / forward / read-back of consecutive batches; the strings must be those of the
+    serial loop (also with a beam decoder and with a user-supplied host decoder)."""
+    from conformer_ocr_amd.ctc_decoder import BeamDecoder
+    hp, state, *_ = case('cfg1')
+    g = np.random.default_rng(6)
+    widths = [int(w) for w in g.integers(25, 90, size=20) * 8]
+    lines = [synth.make_lines(1, hp.height, w, seed=300 + i)[0][0, 0] for i, w in enumerate(widths)]
+    net = _net(hp, state, 'fp32')
+    serial = recognize(net, lines, batch_size=4, pipelined=False)
+    assert recognize(net, lines, batch_size=4, pipelined=True) == serial
+    net.ctc_decoder = BeamDecoder(4)
+    assert recognize(net, lines, batch_size=4, pipelined=True) == recognize(net, lines, batch_size=4, pipelined=False)
+    from oracle.ctc_ref import greedy_decoder as host_greedy
+    net.ctc_decoder = host_greedy                     # any callable (ncls, T) -> records: the reference's host loop
+    assert recognize(net, lines, batch_size=4, pipelined=True) == serial
