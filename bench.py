@@ -119,8 +119,8 @@ def cpu_baseline(hp, state, width, sample_lines):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=60)
-    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--width', type=int, default=1200)
     ap.add_argument('--config', default='cfg2')
