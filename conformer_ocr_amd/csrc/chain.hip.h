@@ -551,20 +551,25 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     // the next epilogue); the normalised rows become the new operand image.
     //   single:  x <- x + staged ;       xn <- LN1(x)
     //   chained: x <- LN1(x + staged) ;  xn <- LN2(x)          (block-final LayerNorm + the next block's first)
-    auto rowln_epilogue = [&](const ChainStage &st) {
+    // The 12 residual rows of this wave's share of the LayerNorm epilogue.  Requested BEFORE the stage's last product step (its
+    // 16 ring refills are then younger: the epilogue waits for these loads only, and their ~2 us of latency pass under the step).
+    struct Resid { f32x4 v[3][4]; };
+    auto load_resid = [&](const ChainStage &st) {
+        Resid r;
+        const int rl = lane >> 4, cl = lane & 15;
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            const int m = min(m0 + 12 * wave + 4 * pass + rl, mend - 1);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                r.v[pass][v] = st.has_resid ? *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return r;
+    };
+    auto rowln_epilogue = [&](const ChainStage &st, const Resid &res) {
         const int rl = lane >> 4, cl = lane & 15;
         const bool chained = st.g2 != nullptr;
-        // all 12 residual rows requested up front (the accumulators are dead here: registers are free); the x stores below
-        // then never sit in front of a load this epilogue waits for
-        f32x4 xr[3][4];
-        if (st.has_resid) {
-#pragma unroll
-            for (int pass = 0; pass < 3; ++pass) {
-                const int m = min(m0 + 12 * wave + 4 * pass + rl, mend - 1);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) xr[pass][v] = *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v));
-            }
-        }
+        const f32x4 (&xr)[3][4] = res.v;
         if (wave < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // this stage's LayerNorm parameters have landed
         lds_fence_barrier();                                 // staged tile complete; every wave is done reading the old image
         constexpr float inv_d = 1.0f / (float)D;
@@ -632,6 +637,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
         if constexpr (kind == ST_ROWLN) {
             request_ln_params(st);
             const Bias2 bb = load_bias(st.bias);
+            const Resid res = load_resid(st);
             f32x4 acc[MT][2];
             zero(acc);
             step(xa, acc, after, no_side);
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             lds_fence_barrier();                             // hs (hidden chunks / output tiles of the previous stage) is free
             stage_rows(acc, bb, st.alpha);
             stamp();
-            rowln_epilogue(st);
+            rowln_epilogue(st, res);
             stamp();
         } else if constexpr (kind == ST_FFN) {
             // Software pipeline over the 256-wide hidden chunks:   P1(c): hidden(c) = xa W1(c)^T  (MFMA)
@@ -687,12 +693,13 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                 stamp();
             }
             const Bias2 b2 = load_bias(st.bias2);
+            const Resid res = load_resid(st);                // (the hidden-chunk accumulators are dead: their registers carry the rows)
             step(hs + ((nchunks - 1) & 1) * IMG, acc2, after, no_side);                  // P2(last)
             stamp();
             lds_fence_barrier();                             // every wave is done reading the hidden chunks
             stage_rows(acc2, b2, st.alpha);
             stamp();
-            rowln_epilogue(st);
+            rowln_epilogue(st, res);
             stamp();
         } else if constexpr (kind == ST_GLU) {
             // two steps of 256 packed columns: wave w's pair = (value tile, gate tile) of channels step*128 + 16w .. +15
