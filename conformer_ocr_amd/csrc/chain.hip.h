@@ -403,6 +403,16 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.dw_in + (size_t)mrow * D + (lane & 31) * 8), (lds_ptr_t)(hs + q2 * 1024), 16, 0, 0);
         }
     }
+    // depthwise taps and bias of this thread's channel pair: requested with the window, ahead of the weight ring (loads return in
+    // order: behind the ring they would wait for all of it, and a second time for their own round trip after the barrier)
+    typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+    dw_f32x2 dw_wt[DWK ? DWK : 1], dw_bias = {0.f, 0.f};
+    if constexpr (DWK != 0) {
+        const int c = 2 * (tid & 127);
+#pragma unroll
+        for (int tau = 0; tau < DWK; ++tau) dw_wt[tau] = *reinterpret_cast<const dw_f32x2 *>(p.dw_w + (size_t)tau * D + c);
+        dw_bias = *reinterpret_cast<const dw_f32x2 *>(p.dw_b + c);
+    }
     // ---- weight ring: the first step's 16 fragments
     bf16x8 ring[16];
     auto fill = [&](const T *slice, int f) { ring[f] = *reinterpret_cast<const bf16x8 *>(slice + f * 512 + lane * 8); };
@@ -439,10 +449,8 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
         const int cp = tid & 127, c = 2 * cp, rq = __builtin_amdgcn_readfirstlane(tid >> 7);
-        f32x2 wt[DWK];
-#pragma unroll
-        for (int tau = 0; tau < DWK; ++tau) wt[tau] = *reinterpret_cast<const f32x2 *>(p.dw_w + (size_t)tau * D + c);
-        const f32x2 bias = *reinterpret_cast<const f32x2 *>(p.dw_b + c);
+        const dw_f32x2 (&wt)[DWK ? DWK : 1] = dw_wt;
+        const f32x2 bias = dw_bias;
         const int T_ = p.T_;
 #pragma unroll 1
         for (int grp = 0; grp < 3; ++grp) {
