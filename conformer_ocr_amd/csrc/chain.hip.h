@@ -24,6 +24,7 @@
 #include "gemm.hip.h"
 
 enum { ST_ROWLN = 0, ST_FFN = 1, ST_GLU = 2, ST_QKV = 3 };
+#define COCR_CHAIN_SMALL_M 4800          // below this many rows the register-streamed chain kernels use 32-row workgroups
 
 struct ChainStage {
     int kind;
@@ -361,10 +362,15 @@ __device__ __forceinline__ float row16_sum(float v) {
 // DWK != 0: the chain starts with the conv module's depthwise conv (kernel DWK, zero padding, BatchNorm folded) + SiLU on the
 // GLU output (convolution.py:140-142), computed for the workgroup's 96 rows from a (96 + DWK - 1)-row window in LDS, result
 // written straight into the operand image -- one launch and one (M, 256) round trip less per block.
-template <int DWK, int K0, int K1, int K2, int K3>
+// MT = 16-row tiles per workgroup: 6 (96 rows: the throughput form) or 2 (32 rows: three times the workgroups for small
+// batches, where the latency of one workgroup's serial chain is the forward's latency).
+template <int MT, int DWK, int K0, int K1, int K2, int K3>
 __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     typedef bf16_t T;
-    constexpr int D = 256, BMC = 96, MT = 6, KC1 = D / 32;
+    static_assert(MT == 6 || MT == 2, "rows per wave in the LayerNorm epilogue must be a multiple of 4");
+    constexpr int D = 256, BMC = 16 * MT, KC1 = D / 32;
+    constexpr int RGH = BMC / 16;              // operand-tile DMA: (4 panels x BMC/8 row groups) / 8 waves wave-instructions per wave
+    constexpr int LNP = BMC / 32;              // LayerNorm epilogue: passes of 4 rows per wave (BMC / 8 rows per wave)
     constexpr int PANEL = BMC * 128;            // one [96 rows][128 B] panel of an operand image (64 bf16 of k per row)
     constexpr int IMG = 4 * PANEL;              // 96 x 256 bf16
     constexpr int RS = D * 4 + 16;              // fp32 staged row (LayerNorm epilogue)
@@ -389,8 +395,8 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     if constexpr (DWK == 0) {
         // ---- first operand tile -> LDS image: 4 panels x 12 row groups of 8 rows = 48 wave-instructions (6 per wave)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = wave + 8 * i, pnl = id / 12, rg = id - pnl * 12, row = rg * 8 + lrow;
+        for (int i = 0; i < RGH; ++i) {
+            const int id = wave + 8 * i, pnl = id / (BMC / 8), rg = id - pnl * (BMC / 8), row = rg * 8 + lrow;
             const T *src = p.A0 + (size_t)min(m0 + row, M - 1) * D + pnl * 64 + ((cpos ^ (row & 7)) * 8);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xa + pnl * PANEL + rg * 1024), 16, 0, 0);
         }
@@ -453,8 +459,8 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
         const f32x2 bias = dw_bias;
         const int T_ = p.T_;
 #pragma unroll 1
-        for (int grp = 0; grp < 3; ++grp) {
-            const int r0 = 24 * rq + 8 * grp;
+        for (int grp = 0; grp < BMC / 32; ++grp) {
+            const int r0 = (BMC / 4) * rq + 8 * grp;
             const int t0 = __builtin_amdgcn_readfirstlane(tpos[r0]);
             f32x2 acc[8];
 #pragma unroll
@@ -561,13 +567,13 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     //   chained: x <- LN1(x + staged) ;  xn <- LN2(x)          (block-final LayerNorm + the next block's first)
     // The 12 residual rows of this wave's share of the LayerNorm epilogue.  Requested BEFORE the stage's last product step (its
     // 16 ring refills are then younger: the epilogue waits for these loads only, and their ~2 us of latency pass under the step).
-    struct Resid { f32x4 v[3][4]; };
+    struct Resid { f32x4 v[LNP][4]; };
     auto load_resid = [&](const ChainStage &st) {
         Resid r;
         const int rl = lane >> 4, cl = lane & 15;
 #pragma unroll
-        for (int pass = 0; pass < 3; ++pass) {
-            const int m = min(m0 + 12 * wave + 4 * pass + rl, mend - 1);
+        for (int pass = 0; pass < LNP; ++pass) {
+            const int m = min(m0 + (BMC / 8) * wave + 4 * pass + rl, mend - 1);
 #pragma unroll
             for (int v = 0; v < 4; ++v)
                 r.v[pass][v] = st.has_resid ? *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v)) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     auto rowln_epilogue = [&](const ChainStage &st, const Resid &res) {
         const int rl = lane >> 4, cl = lane & 15;
         const bool chained = st.g2 != nullptr;
-        const f32x4 (&xr)[3][4] = res.v;
+        const f32x4 (&xr)[LNP][4] = res.v;
         if (wave < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // this stage's LayerNorm parameters have landed
         lds_fence_barrier();                                 // staged tile complete; every wave is done reading the old image
         constexpr float inv_d = 1.0f / (float)D;
@@ -601,8 +607,8 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             }
         };
 #pragma unroll
-        for (int pass = 0; pass < 3; ++pass) {
-            const int row = 12 * wave + 4 * pass + rl;
+        for (int pass = 0; pass < LNP; ++pass) {
+            const int row = (BMC / 8) * wave + 4 * pass + rl;
             const bool live = m0 + row < mend;
             f32x4 t[4];
 #pragma unroll
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             step(xa, acc1, nchunks > 1 ? w1(1) : w2(0), no_side);                      // P1(0)
             stamp();
 #pragma unroll
-            for (int t2 = 0; t2 < 12; ++t2) silu_tile(t2, hs);                            // S(0)
+            for (int t2 = 0; t2 < 2 * MT; ++t2) silu_tile(t2, hs);                        // S(0)
             stamp();
             lds_fence_barrier();
             stamp();
@@ -692,9 +698,9 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                 stamp();
                 unsigned char *hb = hs + (c & 1) * IMG;
                 step(hs + ((c - 1) & 1) * IMG, acc2, c + 1 < nchunks ? w1(c + 1) : w2(c),    // P2(c-1) beside S(c)
-                     [&](auto, int kk) {
-                         if (kk < 4) { silu_tile(2 * kk, hb); silu_tile(2 * kk + 1, hb); }
-                         else silu_tile(4 + kk, hb);
+                     [&](auto, int kk) {                                                  // the 2 MT tiles spread over the 8 k-steps
+#pragma unroll
+                         for (int t2 = 0; t2 < 2 * MT; ++t2) if ((t2 * 8) / (2 * MT) == kk) silu_tile(t2, hb);
                      });
                 stamp();
                 lds_fence_barrier();
@@ -758,7 +764,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                     const int ch = tid & 31, hd = ch * 8, hh = hd / p.dh, d = hd - hh * p.dh;
                     base += (size_t)hh * p.Tp * p.dhp + d;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
+                    for (int i = 0; i < MT; ++i) {
                         const int row = (tid >> 5) + 16 * i;
                         if (m0 + row < mend) copy16(base + rowoff[row], reinterpret_cast<const T *>(tile + row * OS + ch * 16));
                     }
@@ -774,14 +780,19 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     run_stage(std::integral_constant<int, K3>{}, p.st[3], first_slice(0));
 }
 
-template <int DWK, int K0, int K1, int K2, int K3>
-static inline hipError_t launch_chain96_cfg(hipStream_t s, const ChainArgs &a) {
-    const size_t lds = (size_t)3 * 4 * 96 * 128 + 4096 + 4096 + 2048;      // operand image, 2 hidden images (+ slack), LayerNorm parameters, row offsets + frame indices
-    auto kern = chain96_kernel<DWK, K0, K1, K2, K3>;
+template <int MT, int DWK, int K0, int K1, int K2, int K3>
+static inline hipError_t launch_chain96_mt(hipStream_t s, const ChainArgs &a) {
+    const size_t lds = (size_t)3 * 4 * (16 * MT) * 128 + 4096 + 4096 + 2048;      // operand image, 2 hidden images (+ slack), LayerNorm parameters, row offsets + frame indices
+    auto kern = chain96_kernel<MT, DWK, K0, K1, K2, K3>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, 96)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, 16 * MT)), dim3(512), lds, s, a);
     return hipGetLastError();
+}
+// 96-row workgroups when they fill a useful share of the chip (M >= 4800 rows: 50 workgroups), 32-row workgroups below
+template <int DWK, int K0, int K1, int K2, int K3>
+static inline hipError_t launch_chain96_cfg(hipStream_t s, const ChainArgs &a) {
+    return a.M >= COCR_CHAIN_SMALL_M ? launch_chain96_mt<6, DWK, K0, K1, K2, K3>(s, a) : launch_chain96_mt<2, DWK, K0, K1, K2, K3>(s, a);
 }
 
 // the chain shapes the forward uses; stage weights point at the fragment-major copies

@@ -156,3 +156,14 @@ def test_frontend_conv_on_matrix_cores(as_u8, fused, monkeypatch):
         worst[nm] = float(np.abs(got - ref).max() / max(1e-6, np.abs(ref).max()))
     _log(f'frontend_mfma_u8{int(as_u8)}_fused{int(fused)}', worst)
     assert all(v <= 2e-2 for v in worst.values()), worst
+
+
+def test_small_batch_form_of_the_chain_kernels(case):
+    """Below 4800 rows the 96-row chain kernels run as 32-row workgroups (chain.hip.h COCR_CHAIN_SMALL_M).  cfg2 fixture, the
+    first 4 lines only (1200 rows): same logits as the reference within the bf16 band, and -- lines are independent -- the same
+    BITS as lines 0..3 of the full 32-line batch computed by the 96-row form (identical arithmetic per row)."""
+    hp, state, image, lens, g = case('cfg2')
+    dev, mism, eng, small, _ = _check_case(case, 'cfg2', 'bf16', n=4)
+    assert mism == 0 and dev <= 0.35
+    _, full, _ = run_hip(hp, state, image, lens, 'bf16')
+    np.testing.assert_array_equal(small, full[:4])
