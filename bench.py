@@ -128,6 +128,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a captured hipGraph')
+    ap.add_argument('--stagger-us', type=float, default=0.0, help='host-side offset between the first batches of a run (multi-stream only)')
     ap.add_argument('--streams', type=int, default=3, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL at communicator creation) go to stderr
@@ -179,6 +180,8 @@ def main():
     for e in engines:
         e.set_graph(not args.no_graph)
 
+    stagger_s = args.stagger_us * 1e-6 if S > 1 else 0.0
+
     def run_steps(n):
         """n steps; step i is enqueued on stream i % S (forward + greedy decode + D2H of the label records) and its
         records are collected S steps later, so S independent batches overlap on the GPU."""
@@ -188,6 +191,12 @@ def main():
             with torch.cuda.stream(streams[i % S]):
                 logits, out_lens = e.forward(x, lens32, out=outs[i % S])
                 pending.append((e, e.ctc_greedy_async(logits, out_lens)))
+            if i < S - 1 and stagger_s > 0:
+                # the first S batches would start in lockstep (all frontends, then all attention kernels, ... at the same time:
+                # measured 2x the steady-state time for that first group); offset them by a fraction of a step like the steady state
+                t_end = time.perf_counter() + stagger_s
+                while time.perf_counter() < t_end:
+                    pass
             if len(pending) >= S:
                 pe, h = pending.pop(0)
                 recs = pe.collect(h)

@@ -101,7 +101,8 @@ struct cocr_model {
     int vtN = -1, vtT = -1;    // shape the q/k/vt buffers were last zeroed for
     unsigned char *pre_buf = nullptr;      // line pre-processing: descriptors, tap tables, intermediates
     size_t pre_cap = 0;
-    int32_t *d_lens = nullptr;
+    int32_t *d_lens = nullptr, *h_lens = nullptr, *d_lens_cur = nullptr;      // device / pinned-host rings of per-line lengths (upload_lens)
+    int lens_slot = 0;
     int32_t *ctc_lab = nullptr;
     float *ctc_val = nullptr;
     size_t ctc_cap = 0;
@@ -251,6 +252,7 @@ extern "C" void cocr_destroy(cocr_model *m) {
         (void)hipHostFree(m->stamps);
     }
     if (m->d_lens) (void)hipFree(m->d_lens);
+    if (m->h_lens) (void)hipHostFree(m->h_lens);
     if (m->ctc_lab) (void)hipFree(m->ctc_lab);
     if (m->ctc_val) (void)hipFree(m->ctc_val);
     if (m->beam_bp) (void)hipFree(m->beam_bp);
@@ -1041,13 +1043,26 @@ extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, in
 }
 
 // ------------------------------------------------------------------------------------ CTC
+// The per-line lengths reach the decode kernels through a PINNED host ring: an async copy from pageable memory goes through the
+// runtime's staging buffers, and a third such copy in flight (three batches on three streams, each copy queued behind its
+// forward) blocked the host until the first forward had finished -- 5.5 ms per run start.  Slots are reused after
+// COCR_LENS_SLOTS further decode calls of this model (one model = one stream = a handful of calls in flight at most).
+#define COCR_LENS_SLOTS 16
 static int upload_lens(cocr_model *m, const int32_t *lens, int N, hipStream_t s) {
     if (N > m->lens_cap) {
         if (m->d_lens) (void)hipFree(m->d_lens);
-        HIP_TRY(hipMalloc((void **)&m->d_lens, (size_t)N * 4));
+        if (m->h_lens) (void)hipHostFree(m->h_lens);
+        HIP_TRY(hipMalloc((void **)&m->d_lens, (size_t)N * 4 * COCR_LENS_SLOTS));
+        HIP_TRY(hipHostMalloc((void **)&m->h_lens, (size_t)N * 4 * COCR_LENS_SLOTS));
         m->lens_cap = N;
+        m->lens_slot = 0;
     }
-    HIP_TRY(hipMemcpyAsync(m->d_lens, lens, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    const int slot = m->lens_slot;
+    m->lens_slot = (slot + 1) % COCR_LENS_SLOTS;
+    int32_t *h = m->h_lens + (size_t)slot * m->lens_cap;
+    memcpy(h, lens, (size_t)N * 4);
+    m->d_lens_cur = m->d_lens + (size_t)slot * m->lens_cap;
+    HIP_TRY(hipMemcpyAsync(m->d_lens_cur, h, (size_t)N * 4, hipMemcpyHostToDevice, s));
     return COCR_OK;
 }
 
@@ -1068,9 +1083,9 @@ extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T,
         m->ctc_cap = (size_t)N * T;
     }
     ProfScope ps(m, s, FAM_GREEDY);
-    hipLaunchKernelGGL(ctc_argmax_kernel, dim3(ceil_div(N * T, 4)), dim3(256), 0, s, logits, T, ncls, N * T, m->d_lens, m->ctc_lab, m->ctc_val);
+    hipLaunchKernelGGL(ctc_argmax_kernel, dim3(ceil_div(N * T, 4)), dim3(256), 0, s, logits, T, ncls, N * T, m->d_lens_cur, m->ctc_lab, m->ctc_val);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(64), (size_t)T * 8, s, T, m->d_lens, m->ctc_lab, m->ctc_val, labels, starts, ends, conf, counts,
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(64), (size_t)T * 8, s, T, m->d_lens_cur, m->ctc_lab, m->ctc_val, labels, starts, ends, conf, counts,
                        max_per_line);
     LAUNCH_CHECK();
     return COCR_OK;
@@ -1100,13 +1115,13 @@ extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, i
     if (fast) {
         float *lp_all = logz + (size_t)N * T;
         int32_t *topc = reinterpret_cast<int32_t *>(lp_all + (size_t)N * T * ncls);
-        hipLaunchKernelGGL(ctc_beam2_kernel, dim3(N), dim3(256), 0, s, logits, T, ncls, m->d_lens, beam, labels, starts, ends, conf, counts, max_per_line,
+        hipLaunchKernelGGL(ctc_beam2_kernel, dim3(N), dim3(256), 0, s, logits, T, ncls, m->d_lens_cur, beam, labels, starts, ends, conf, counts, max_per_line,
                            lp_all, topc, bp, logz, m->stamps ? m->stamps + 240 : nullptr);
     } else {
         const size_t lds = ((size_t)ncls + (size_t)beam * ncls) * 4 + COCR_BEAM_MAX * (11 * 4 + 2 * 8) + 64;
         if (lds > 150 * 1024) return fail(COCR_EUNSUPPORTED, "beam x classes too large for the LDS candidate table");
         HIP_TRY(raise_lds_limit((const void *)ctc_beam_kernel, lds));
-        hipLaunchKernelGGL(ctc_beam_kernel, dim3(N), dim3(64), lds, s, logits, T, ncls, m->d_lens, beam, labels, starts, ends, conf, counts,
+        hipLaunchKernelGGL(ctc_beam_kernel, dim3(N), dim3(64), lds, s, logits, T, ncls, m->d_lens_cur, beam, labels, starts, ends, conf, counts,
                            max_per_line, bp, logz);
     }
     LAUNCH_CHECK();

@@ -149,31 +149,29 @@ class HipRecognizer:
         return logits, out_lens
 
     def _decode_async(self, fn, logits: torch.Tensor, out_lens, extra=()):
-        """Enqueues the decode kernel and the device->host copy of the compact records on the current stream;
-        returns a handle for `collect` (pinned host buffers + an event)."""
+        """Enqueues the decode kernel on the current stream, its outputs in pinned host memory; returns a handle for `collect`
+        (the pinned buffers + an event)."""
         if logits.device != self.device or logits.dtype != torch.float32:
             raise RuntimeError('logits must be float32 on the model device')
         logits = logits.contiguous()
         N, T, ncls = logits.shape
         lens = np.ascontiguousarray(np.asarray(out_lens, dtype=np.int32).reshape(-1))
-        ints = torch.empty((3, N, T), dtype=torch.int32, device=self.device)
-        conf = torch.empty((N, T), dtype=torch.float32, device=self.device)
-        counts = torch.empty((N,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(fn(self._h, C.c_void_p(logits.data_ptr()), N, T, ncls, lens.ctypes.data_as(C.POINTER(C.c_int32)),
-                          C.c_void_p(ints[0].data_ptr()), C.c_void_p(ints[1].data_ptr()), C.c_void_p(ints[2].data_ptr()),
-                          C.c_void_p(conf.data_ptr()), C.c_void_p(counts.data_ptr()), T, *extra, _stream_ptr(self.device)))
+            # The decode kernels write their (sparse) label records STRAIGHT into pinned host memory (device-visible): no
+            # device->host copy is enqueued.  A third hipMemcpyAsync D2H in flight (three batches on three streams, each queued
+            # behind its forward) blocked the host for a whole forward, 5.5 ms at every start of a run.
             key = (N, T)
             pool = self._pinned.setdefault(key, [])
             host = pool.pop() if pool else (torch.empty((3, N, T), dtype=torch.int32).pin_memory(),
                                             torch.empty((N, T), dtype=torch.float32).pin_memory(),
                                             torch.empty((N,), dtype=torch.int32).pin_memory())
-            host[0].copy_(ints, non_blocking=True)
-            host[1].copy_(conf, non_blocking=True)
-            host[2].copy_(counts, non_blocking=True)
+            ints, conf, counts = host
+            _lib.check(fn(self._h, C.c_void_p(logits.data_ptr()), N, T, ncls, lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                          C.c_void_p(ints[0].data_ptr()), C.c_void_p(ints[1].data_ptr()), C.c_void_p(ints[2].data_ptr()),
+                          C.c_void_p(conf.data_ptr()), C.c_void_p(counts.data_ptr()), T, *extra, _stream_ptr(self.device)))
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
-        return (key, host, ev, (ints, conf, counts, logits))
+        return (key, host, ev, (logits,))
 
     def collect(self, handle) -> List[List[Tuple[int, int, int, float]]]:
         """Waits for a `_decode_async` handle and builds the per-line (label, start, end, conf) lists."""
