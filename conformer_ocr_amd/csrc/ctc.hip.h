@@ -277,7 +277,12 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // maximum of 64-bit keys as two 32-bit maxima: the score word first, then the position word among the lanes that hold it
 __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
     const unsigned hi = (unsigned)(v >> 32), mhi = wave_max_u32(hi);
-    const unsigned lo = hi == mhi ? (unsigned)v : 0u, mlo = wave_max_u32(lo);
+    const unsigned long long owners = __builtin_amdgcn_ballot_w64(hi == mhi);
+    unsigned mlo;
+    if (__builtin_popcountll(owners) == 1)                   // the usual case: one lane holds the best score -- its position by v_readlane
+        mlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, (int)__builtin_ctzll(owners));
+    else
+        mlo = wave_max_u32(hi == mhi ? (unsigned)v : 0u);    // equal scores: the smallest position (largest ~position) wins
     return ((unsigned long long)mhi << 32) | mlo;
 }
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
