@@ -74,8 +74,8 @@ def pmc_traffic(family):
     import glob
     names = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12',
              'frontend_fused': 'frontend96_kernel',
-             'chain_pw2_ffn_ffn_qkv': 'chain96_kernel<31, 0, 1, 1, 3>', 'chain_attn_out_glu': 'chain96_kernel<0, 0, 2, -1, -1>',
-             'chain_ffn_qkv': 'chain96_kernel<0, 1, 3, -1, -1>', 'chain_pw2_ffn': 'chain96_kernel<31, 0, 1, -1, -1>'}
+             'chain_pw2_ffn_ffn_qkv': 'chain96_kernel<6, 31, 0, 1, 1, 3>', 'chain_attn_out_glu': 'chain96_kernel<6, 0, 0, 2, -1, -1>',
+             'chain_ffn_qkv': 'chain96_kernel<6, 0, 1, 3, -1, -1>', 'chain_pw2_ffn': 'chain96_kernel<6, 31, 0, 1, -1, -1>'}
     if family not in names:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.csv')))
