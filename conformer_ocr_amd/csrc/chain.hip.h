@@ -737,7 +737,6 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             lds_fence_barrier();
             flush_tile(hs, 0, [&](int m, int c, const T *src) { e.store(m, c, src, 8); });
         } else if constexpr (kind == ST_QKV) {   // three steps of 256 columns
-            EpiQKV<T> e{st.q, st.k, st.v, st.bias, D, p.dh, p.dhp, p.heads, p.T_, p.Tp, 3 * D};
             lds_fence_barrier();                             // hs free
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
