@@ -351,11 +351,11 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t *__restrict
 }
 
 // sum over each 16-lane row of the wave (4 DPP steps), result in every lane of the row
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_f32<0xB1, 0xF>(v, 0.f);      // quad_perm(1,0,3,2)
-    v += dpp_f32<0x4E, 0xF>(v, 0.f);      // quad_perm(2,3,0,1)
-    v += dpp_f32<0x141, 0xF>(v, 0.f);     // row_half_mirror
-    v += dpp_f32<0x140, 0xF>(v, 0.f);     // row_mirror
+__device__ __forceinline__ float row16_sum(float v) {      // (every lane is written by these patterns: `old` = v spares a v_mov per step)
+    v += dpp_f32<0xB1, 0xF>(v, v);        // quad_perm(1,0,3,2)
+    v += dpp_f32<0x4E, 0xF>(v, v);        // quad_perm(2,3,0,1)
+    v += dpp_f32<0x141, 0xF>(v, v);       // row_half_mirror
+    v += dpp_f32<0x140, 0xF>(v, v);       // row_mirror
     return v;
 }
 
@@ -589,21 +589,19 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
         constexpr float inv_d = 1.0f / (float)D;
         auto normalise = [&](f32x4 (&t)[4], int which) {     // which: 0 = (g1, b1), 1 = (g2, b2)
             const float *ga = lnp + which * 512, *be = ga + 256;
-            float s = 0.f;
+            // packed arithmetic throughout (the epilogue is VALU-issue bound): 4-wide partial sums, one horizontal add each
+            f32x4 s4 = (t[0] + t[1]) + (t[2] + t[3]);
+            const float mean = row16_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_d;
+            const f32x4 m4 = {mean, mean, mean, mean};
+            f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int v = 0; v < 4; ++v) s += (t[v][0] + t[v][1]) + (t[v][2] + t[v][3]);
-            const float mean = row16_sum(s) * inv_d;
-            float q = 0.f;
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { t[v][e] -= mean; q += t[v][e] * t[v][e]; }
-            const float rstd = __builtin_amdgcn_rsqf(row16_sum(q) * inv_d + 1e-5f);
+            for (int v = 0; v < 4; ++v) { t[v] -= m4; q4 += t[v] * t[v]; }
+            const float rstd = __builtin_amdgcn_rsqf(row16_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * inv_d + 1e-5f);
+            const f32x4 r4 = {rstd, rstd, rstd, rstd};
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const f32x4 gv = *reinterpret_cast<const f32x4 *>(ga + 4 * (cl + 16 * v)), bv = *reinterpret_cast<const f32x4 *>(be + 4 * (cl + 16 * v));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[v][e] = t[v][e] * rstd * gv[e] + bv[e];
+                t[v] = t[v] * (r4 * gv) + bv;
             }
         };
 #pragma unroll
@@ -613,8 +611,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             f32x4 t[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                t[v] = *reinterpret_cast<const f32x4 *>(hs + row * RS + 16 * (cl + 16 * v));
-                if (st.has_resid) t[v] += xr[pass][v];
+                t[v] = *reinterpret_cast<const f32x4 *>(hs + row * RS + 16 * (cl + 16 * v)) + xr[pass][v];      // (zeros without a residual)
             }
             float *xrow = p.x + (size_t)(m0 + row) * D;
             if (!chained) {
