@@ -48,6 +48,7 @@ struct ChainArgs {
     int M, nstages;
     const bf16_t *dw_in;   // 96-row form with the depthwise-conv prologue: GLU output (M, 256); A0 unused
     const float *dw_w, *dw_b;      // BatchNorm-folded depthwise taps [k][256] and bias [256]
+    float *dump;           // >= 16 KiB scratch: branch-free sink for the stores of rows beyond M (16 bytes per thread + slack)
     unsigned long long *stamps;   // dev: cycle stamps of workgroup 0 / wave 0 (COCR_CHAIN_STAMPS), else null
     int dh, dhp, heads, T_, Tp;       // attention layout of the QKV stage
     ChainStage st[4];
@@ -604,35 +605,43 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                 t[v] = t[v] * (r4 * gv) + bv;
             }
         };
+        // One basic block for all passes (no branch inside: rows beyond M and the optional xn copy store through selected addresses
+        // into a dump area), so that the scheduler interleaves the passes' dependent chains (LDS read -> row reduction by DPP ->
+        // centre -> row reduction -> scale): with a branch per store the passes ran strictly one after the other.
+        auto passes = [&](auto CH) {
+            constexpr bool chained_c = decltype(CH)::value;
 #pragma unroll
-        for (int pass = 0; pass < LNP; ++pass) {
-            const int row = (BMC / 8) * wave + 4 * pass + rl;
-            const bool live = m0 + row < mend;
-            f32x4 t[4];
+            for (int pass = 0; pass < LNP; ++pass) {
+                const int row = (BMC / 8) * wave + 4 * pass + rl;
+                const bool live = m0 + row < mend;
+                f32x4 t[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                t[v] = *reinterpret_cast<const f32x4 *>(hs + row * RS + 16 * (cl + 16 * v)) + xr[pass][v];      // (zeros without a residual)
+                for (int v = 0; v < 4; ++v)
+                    t[v] = *reinterpret_cast<const f32x4 *>(hs + row * RS + 16 * (cl + 16 * v)) + xr[pass][v];      // (zeros without a residual)
+                float *xrow = live ? p.x + (size_t)(m0 + row) * D + 4 * cl : p.dump + 4 * tid;
+                const int xstep = live ? 64 : 0;
+                if constexpr (!chained_c) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + xstep * v) = t[v];
+                    normalise(t, 0);
+                } else {
+                    normalise(t, 0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + xstep * v) = t[v];
+                    normalise(t, 1);
+                }
+                const bool wxn = live && st.store_xn;
+                T *nrow = wxn ? p.xn + (size_t)(m0 + row) * D + 4 * cl : reinterpret_cast<T *>(p.dump + 4 * tid);
+                const int nstep = wxn ? 64 : 0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bf16x4 o = {(T)t[v][0], (T)t[v][1], (T)t[v][2], (T)t[v][3]};
+                    *reinterpret_cast<bf16x4 *>(xa + v * PANEL + row * 128 + ((((cl >> 1) ^ (row & 7))) << 4) + (cl & 1) * 8) = o;
+                    *reinterpret_cast<bf16x4 *>(nrow + nstep * v) = o;
+                }
             }
-            float *xrow = p.x + (size_t)(m0 + row) * D;
-            if (!chained) {
-                if (live)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + 4 * (cl + 16 * v)) = t[v];
-                normalise(t, 0);
-            } else {
-                normalise(t, 0);
-                if (live)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + 4 * (cl + 16 * v)) = t[v];
-                normalise(t, 1);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const bf16x4 o = {(T)t[v][0], (T)t[v][1], (T)t[v][2], (T)t[v][3]};
-                *reinterpret_cast<bf16x4 *>(xa + v * PANEL + row * 128 + ((((cl >> 1) ^ (row & 7))) << 4) + (cl & 1) * 8) = o;
-                if (st.store_xn && live) *reinterpret_cast<bf16x4 *>(p.xn + (size_t)(m0 + row) * D + 4 * (cl + 16 * v)) = o;
-            }
-        }
+        };
+        if (chained) passes(std::true_type{}); else passes(std::false_type{});
         lds_fence_barrier();                                 // new operand image complete, staging consumed
     };
     // cooperative, coalesced copy of a staged bf16 [96][256] tile (row stride OS) to global through `store`

@@ -101,6 +101,7 @@ struct cocr_model {
     int vtN = -1, vtT = -1;    // shape the q/k/vt buffers were last zeroed for
     unsigned char *pre_buf = nullptr;      // line pre-processing: descriptors, tap tables, intermediates
     size_t pre_cap = 0;
+    void *dump = nullptr;      // 16 KiB sink for predicated-off stores of the chain kernels
     int32_t *d_lens = nullptr, *h_lens = nullptr, *d_lens_cur = nullptr;      // device / pinned-host rings of per-line lengths (upload_lens)
     int lens_slot = 0;
     int32_t *ctc_lab = nullptr;
@@ -567,6 +568,7 @@ extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
     const size_t M = (size_t)N * T, Tp = round_up(T, 32);
     int rc;
     const size_t zbytes = (size_t)N * T2 * m->feats[1] * m->C * es;
+    if ((rc = ws_alloc(m, &m->dump, 16384))) return rc;
     if ((rc = ws_alloc(m, &m->z_a, zbytes))) return rc;
     if ((rc = ws_alloc(m, &m->z_b, zbytes))) return rc;
     if ((rc = ws_alloc(m, (void **)&m->x, M * m->D * 4))) return rc;
@@ -829,7 +831,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             const unsigned char *CW = c96 ? m->packed : B;       // chain weights: fragment-major copies or the row-major blob
             auto CWT = [&](size_t off) { return (const bf16_t *)(CW + off); };
             auto launch = [&](const ChainArgs &a) { return c96 ? launch_chain96(s, a) : launch_chain(s, a, ff); };
-            auto base = [&]() { ChainArgs a{}; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
+            auto base = [&]() { ChainArgs a{}; a.dump = (float *)m->dump; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
             auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
                 ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha; st.has_resid = 1;
                 st.g1 = F32(g1); st.b1 = F32(b1); return st; };
