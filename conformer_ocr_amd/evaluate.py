@@ -114,6 +114,33 @@ def recognize(net, lines: Sequence[np.ndarray], batch_size: int = 32, edge: int 
     return out
 
 
+def recognize_crops(net, crops: Sequence[np.ndarray], batch_size: int = 32, edge: int = 200, pad: int = 16, rank: int = 0, world: int = 1,
+                    device: str = 'cuda:0') -> Dict[int, str]:
+    """The same loop starting one step earlier: `crops` are raw 8-bit line images ((H, W) grayscale or (H, W, 3) RGB, any height).
+    Scaling to the model height, padding and collation run on the GPU (`net.transform_lines`, the reference pipeline's
+    `ImageInputTransforms`); buckets are formed from the widths the lines will have after scaling, so a line's batch -- hence
+    its string -- is the one `recognize` gives for the pre-processed line."""
+    from . import _lib
+    lib = _lib.load()
+    widths = [int(lib.cocr_preproc_width(int(c.shape[0]), int(c.shape[1]), int(net.height), int(pad))) for c in crops]
+    batches = make_batches(widths, batch_size, edge)
+    out: Dict[int, str] = {}
+    pending = None
+    for b in shard_batches(len(batches), rank, world):
+        width, idx = batches[b]
+        im, lens = net.transform_lines([crops[i] for i in idx], pad=pad, bucket_edge=edge, device=device)
+        assert im.shape[3] == width, (im.shape, width)
+        handle = net.predict_string_async(im, lens)
+        if pending is not None:
+            for i, s in zip(pending[0], net.collect_strings(pending[1])):
+                out[i] = s
+        pending = (idx, handle)
+    if pending is not None:
+        for i, s in zip(pending[0], net.collect_strings(pending[1])):
+            out[i] = s
+    return out
+
+
 def evaluate(net, lines: Sequence[np.ndarray], truths: Sequence[str], **kw) -> Dict[str, float]:
     """CER / WER of `net` on (lines, truths): the report of cli/test.py:211-212."""
     pred = recognize(net, lines, **kw)

@@ -55,3 +55,21 @@ def test_pipelined_loop_equals_serial_loop(case):
     from oracle.ctc_ref import greedy_decoder as host_greedy
     net.ctc_decoder = host_greedy                     # any callable (ncls, T) -> records: the reference's host loop
     assert recognize(net, lines, batch_size=4, pipelined=True) == serial
+
+
+def test_recognize_from_raw_crops(case):
+    """recognize_crops = GPU pre-processing + the recognition loop: same strings as `recognize` on the lines the pre-processing
+    oracle produces from the same crops."""
+    from conformer_ocr_amd.evaluate import recognize_crops
+    from oracle import preproc_ref as P
+    hp, state, *_ = case('cfg1')
+    g = np.random.default_rng(17)
+    crops = []
+    for i in range(14):
+        h, w = int(g.integers(40, 160)), int(g.integers(200, 900))
+        c = g.integers(0, 256, size=(h, w) if i % 3 else (h, w, 3), dtype=np.uint8)
+        crops.append(c)
+    net = _net(hp, state, 'fp32')
+    got = recognize_crops(net, crops, batch_size=4)
+    lines = [P.preprocess_line(c, hp.height, 16).astype(np.float32) / 255.0 for c in crops]
+    assert got == recognize(net, lines, batch_size=4)
