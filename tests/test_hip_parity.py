@@ -167,3 +167,21 @@ def test_small_batch_form_of_the_chain_kernels(case):
     assert mism == 0 and dev <= 0.35
     _, full, _ = run_hip(hp, state, image, lens, 'bf16')
     np.testing.assert_array_equal(small, full[:4])
+
+
+@pytest.mark.parametrize('n,w', [(1, 17), (2, 33), (3, 100), (5, 513), (7, 1023), (2, 2048), (160, 120)])
+def test_cfg2_kernels_on_odd_shapes(n, w):
+    """The measured configuration's kernels (fused frontend, 96- / 32-row chains, rel-pos attention) on awkward batch shapes:
+    one frame groups that are not multiples of 4, a single line, very short and very long lines, more rows than one launch
+    of the small form covers.  One block, bf16 against the fp32 oracle; logits within the bf16 band."""
+    from conformer_ocr_amd import synth
+    hp = synth.hparams('cfg2', num_encoder_layers=1)
+    state = synth.make_state_dict(hp, seed=99, decoder_gain=8.0)
+    widths = [max(9, w - 13 * i) for i in range(n)]
+    image, lens = synth.make_lines(n, hp.height, w, seed=n * 131 + w, widths=widths)
+    eng, logits, out_lens = run_hip(hp, state, image, lens, 'bf16')
+    ref, ref_lens, _ = oracle_taps(hp, state, image, lens)
+    assert out_lens.tolist() == ref_lens.tolist()
+    dev = float(np.abs(logits - ref).max())
+    _log(f'cfg2_1block_n{n}_w{w}', {'max_abs_logit_dev': dev, 'logit_range': float(np.abs(ref).max())})
+    assert dev <= 0.25, dev
