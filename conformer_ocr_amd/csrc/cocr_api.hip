@@ -800,7 +800,10 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     // K = F*C (6144) against N = D: split-K over 2 workgroup groups (2 measured best of 2, 4, 8: 63 vs 74 vs 91 us for product + reduction) (partials in the idle frontend buffer), then one pass
     // sums them, adds the bias and applies the first block's LayerNorm.
     {
-        constexpr int SPLITS = 2;
+#ifndef COCR_FO_SPLITS
+#define COCR_FO_SPLITS 2
+#endif
+        constexpr int SPLITS = COCR_FO_SPLITS;
         const int Kf = F * C;
         const bool splitk = rowln && !m->debug && (Kf % (SPLITS * (128 / (int)sizeof(T))) == 0) && D <= 256 &&
                             (size_t)SPLITS * M * D * 4 <= (size_t)N * T2 * F2 * C * sizeof(T);

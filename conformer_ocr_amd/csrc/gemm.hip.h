@@ -743,17 +743,23 @@ static inline hipError_t launch_gemm_rowln(hipStream_t s, const T *A, int lda, c
 
 // Split-K product for the frontend output linear (M x 256 x 6144): `splits` partial sums [z][M][N] fp32 (no bias), summed by
 // splitk_reduce_ln_kernel.  One launch, grid.y = splits; 128 x 128 tiles.
+#ifndef COCR_FO_BM
+#define COCR_FO_BM 128
+#define COCR_FO_BN 128
+#define COCR_FO_NST 2
+#endif
 template <typename T>
 static inline hipError_t launch_gemm_splitk(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, int splits, float *partial) {
     constexpr int BK = 128 / (int)sizeof(T);
+    constexpr int BM = COCR_FO_BM, BN = COCR_FO_BN, NST = COCR_FO_NST;
     if (K % (splits * BK)) return hipErrorInvalidValue;
     GemmArgs<T> a{A, lda, W, ldw, M, N, K / splits, K / splits};
     EpiStoreF32 e{partial, N, nullptr, N};
     e.zstride = (size_t)M * N;
-    const size_t lds = std::max((size_t)2 * (128 + 128) * 128, epi_lds_bytes<EpiStoreF32, 128, 128>());
-    auto kern = gemm_ring_kernel<T, 128, 128, 2, EpiStoreF32>;
+    const size_t lds = std::max((size_t)NST * (BM + BN) * 128, epi_lds_bytes<EpiStoreF32, BM, BN>());
+    auto kern = gemm_ring_kernel<T, BM, BN, NST, EpiStoreF32>;
     hipError_t err = raise_lds_limit((const void *)kern, lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(N, 128) * ceil_div(M, 128), splits), dim3(256), lds, s, a, e);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(N, BN) * ceil_div(M, BM), splits), dim3(256), lds, s, a, e);
     return hipGetLastError();
 }
