@@ -41,6 +41,7 @@ SYMBOLS = {
     'cocr_forward': (_I, [_P, _P, _I, _I, _I, _I, _I32P, _P, _I32P, _P]),
     'cocr_ctc_greedy': (_I, [_P, _P, _I, _I, _I, _I32P, _P, _P, _P, _P, _P, _I, _P]),
     'cocr_ctc_beam': (_I, [_P, _P, _I, _I, _I, _I32P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'cocr_ctc_loss': (_I, [_P, _P, _I, _I, _I, _I32P, _I32P, _I32P, _P, _P, _P]),
     'cocr_preproc_width': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'cocr_preproc_lines': (_I, [_P, _P, C.POINTER(C.c_int64), _I32P, _I32P, _I32P, _I, _I, _I, _I, _P, _I32P, _P]),
     'cocr_set_graph': (_I, [_P, _I]),

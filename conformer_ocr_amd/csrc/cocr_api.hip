@@ -21,6 +21,7 @@
 #include "common.hip.h"
 #include "conv.hip.h"
 #include "ctc.hip.h"
+#include "ctc_loss.hip.h"
 #include "gemm.hip.h"
 #include "ffn.hip.h"
 #include "chain.hip.h"
@@ -110,6 +111,11 @@ struct cocr_model {
     int32_t *beam_bp = nullptr;
     size_t beam_cap = 0;
     int lens_cap = 0;
+    int32_t *loss_d = nullptr, *loss_h = nullptr;      // cocr_ctc_loss: device / pinned-host rings of [lens | label lens | label offsets | labels]
+    size_t loss_ints = 0;
+    int loss_slot = 0;
+    float *loss_ws = nullptr;                          // log-softmax + alpha / beta tables
+    size_t loss_ws_cap = 0;
     // debug / profile
     // hipGraph replay of the forward's launch sequence, keyed by the call's shapes and buffers
     bool use_graph = false;
@@ -132,9 +138,9 @@ struct cocr_model {
 
 static const char *FAMILIES[] = {"frontend_fused", "frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
                                  "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "chain_ffn_qkv", "chain_attn_out_glu", "chain_pw2_ffn_ffn_qkv", "chain_pw2_ffn", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
-                                 "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam"};
+                                 "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam", "ctc_loss"};
 enum { FAM_FRONT96, FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_CH_FIRST, FAM_CH_A, FAM_CH_B, FAM_CH_LAST, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
-       FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_COUNT };
+       FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_LOSS, FAM_COUNT };
 
 static int out_len1(int l) { return l >= 1 ? (l - 1) / 2 + 1 : 0; }
 
@@ -257,6 +263,9 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->ctc_lab) (void)hipFree(m->ctc_lab);
     if (m->ctc_val) (void)hipFree(m->ctc_val);
     if (m->beam_bp) (void)hipFree(m->beam_bp);
+    if (m->loss_d) (void)hipFree(m->loss_d);
+    if (m->loss_h) (void)hipHostFree(m->loss_h);
+    if (m->loss_ws) (void)hipFree(m->loss_ws);
     for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
@@ -1129,6 +1138,61 @@ extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, i
         hipLaunchKernelGGL(ctc_beam_kernel, dim3(N), dim3(64), lds, s, logits, T, ncls, m->d_lens_cur, beam, labels, starts, ends, conf, counts,
                            max_per_line, bp, logz);
     }
+    LAUNCH_CHECK();
+    return COCR_OK;
+}
+
+// ------------------------------------------------------------------------------------ CTC loss (ctc_loss.hip.h)
+extern "C" int cocr_ctc_loss(cocr_model *m, const float *probits, int N, int T, int ncls, const int32_t *out_lens, const int32_t *targets,
+                             const int32_t *label_lens, float *nll, float *grad, void *stream) {
+    if (!m || !probits || !out_lens || !label_lens || !nll) return fail(COCR_EINVAL, "null argument");
+    if (N < 1 || T < 1 || ncls < 2) return fail(COCR_EINVAL, "empty problem");
+    if (ncls > 16384) return fail(COCR_EUNSUPPORTED, "more than 16384 classes");
+    size_t total = 0;
+    int max_l = 0;
+    for (int n = 0; n < N; ++n) {
+        if (label_lens[n] < 0) return fail(COCR_EINVAL, "negative target length (line %d)", n);
+        if (label_lens[n] > COCR_CTCL_MAX_LABELS) return fail(COCR_EUNSUPPORTED, "line %d has %d labels; the kernel holds at most %d", n, label_lens[n], COCR_CTCL_MAX_LABELS);
+        if (out_lens[n] < 0 || out_lens[n] > T) return fail(COCR_EINVAL, "input length %d outside [0, %d] (line %d)", out_lens[n], T, n);
+        max_l = std::max(max_l, (int)label_lens[n]);
+        total += (size_t)label_lens[n];
+    }
+    if (total && !targets) return fail(COCR_EINVAL, "null argument");
+    for (size_t i = 0; i < total; ++i)
+        if (targets[i] < 1 || targets[i] >= ncls) return fail(COCR_EINVAL, "target %d outside [1, %d) (blank is 0)", targets[i], ncls);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ints = (size_t)3 * N + total;
+    if (ints > m->loss_ints) {
+        if (m->loss_d) (void)hipFree(m->loss_d);
+        if (m->loss_h) (void)hipHostFree(m->loss_h);
+        m->loss_d = m->loss_h = nullptr;
+        m->loss_ints = 0;
+        const size_t cap = ints + ints / 2;
+        HIP_TRY(hipMalloc((void **)&m->loss_d, cap * 4 * COCR_LENS_SLOTS));
+        HIP_TRY(hipHostMalloc((void **)&m->loss_h, cap * 4 * COCR_LENS_SLOTS));
+        m->loss_ints = cap;
+        m->loss_slot = 0;
+    }
+    const int slot = m->loss_slot;
+    m->loss_slot = (slot + 1) % COCR_LENS_SLOTS;
+    int32_t *h = m->loss_h + (size_t)slot * m->loss_ints, *d = m->loss_d + (size_t)slot * m->loss_ints;
+    int32_t off = 0;
+    for (int n = 0; n < N; ++n) { h[n] = out_lens[n]; h[N + n] = label_lens[n]; h[2 * N + n] = off; off += label_lens[n]; }
+    if (total) memcpy(h + 3 * N, targets, total * 4);
+    HIP_TRY(hipMemcpyAsync(d, h, ints * 4, hipMemcpyHostToDevice, s));
+    const int states = 2 * max_l + 1;
+    const int sj = states <= 64 ? 1 : states <= 128 ? 2 : states <= 256 ? 4 : 8;
+    const size_t need = (size_t)N * T * ((size_t)ncls + 2 * 64 * sj);
+    if (need > m->loss_ws_cap) {
+        if (m->loss_ws) (void)hipFree(m->loss_ws);
+        m->loss_ws = nullptr;
+        m->loss_ws_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->loss_ws, need * 4));
+        m->loss_ws_cap = need;
+    }
+    ProfScope ps(m, s, FAM_LOSS);
+    launch_ctc_loss(s, sj, (size_t)ncls * 4, probits, N, T, ncls, d, d + N, d + 2 * N, d + 3 * N, nll, grad, m->loss_ws, m->loss_ws + (size_t)N * T * ncls);
     LAUNCH_CHECK();
     return COCR_OK;
 }

@@ -198,6 +198,32 @@ class HipRecognizer:
     def ctc_beam(self, logits: torch.Tensor, out_lens, beam: int = 16) -> List[List[Tuple[int, int, int, float]]]:
         return self._decode(self.lib.cocr_ctc_beam, logits, out_lens, extra=(int(beam),))
 
+    def ctc_loss(self, probits: torch.Tensor, out_lens, targets, label_lens, with_grad: bool = True):
+        """nn.CTCLoss(reduction='sum', zero_infinity=True) on log_softmax(probits) (reference model.py:119,136-142) on the device.
+        probits (N,T,ncls) float32 on this device; out_lens (N) valid frames; targets: the batch's concatenated 1-D label vector,
+        label_lens (N) its per-line lengths (host sequences).  Returns (per-line nll (N) float32 device tensor -- 0 where no
+        alignment exists --, d sum(nll) / d probits (N,T,ncls) or None); the reference's loss is `nll.sum()`.  Stream-ordered."""
+        if probits.device != self.device or probits.dtype != torch.float32 or probits.dim() != 3:
+            raise RuntimeError('probits must be a float32 (N,T,num_classes) tensor on the model device')
+        probits = probits.contiguous()
+        N, T, ncls = probits.shape
+        lens = np.ascontiguousarray(np.asarray(out_lens, dtype=np.int32).reshape(-1))
+        tl = np.ascontiguousarray(np.asarray(label_lens, dtype=np.int32).reshape(-1))
+        tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32).reshape(-1))
+        if lens.shape[0] != N or tl.shape[0] != N:
+            raise ValueError('out_lens and label_lens need one entry per line')
+        if int(tl.sum()) != tg.shape[0]:
+            raise ValueError('targets must hold sum(label_lens) labels')
+        nll = torch.empty((N,), dtype=torch.float32, device=self.device)
+        grad = torch.empty_like(probits) if with_grad else None
+        i32 = C.POINTER(C.c_int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_ctc_loss(self._h, C.c_void_p(probits.data_ptr()), N, T, ncls, lens.ctypes.data_as(i32),
+                                              tg.ctypes.data_as(i32) if tg.shape[0] else None, tl.ctypes.data_as(i32),
+                                              C.c_void_p(nll.data_ptr()), C.c_void_p(grad.data_ptr()) if with_grad else None,
+                                              _stream_ptr(self.device)))
+        return nll, grad
+
     # ---- line pre-processing (include/cocr.h: cocr_preproc_lines) --------------------------------------
     def preprocess(self, lines: Sequence[np.ndarray], height: Optional[int] = None, pad: int = 16, width: int = 0,
                    bucket_edge: int = 0) -> Tuple[torch.Tensor, np.ndarray]:

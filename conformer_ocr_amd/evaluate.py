@@ -149,3 +149,44 @@ def evaluate(net, lines: Sequence[np.ndarray], truths: Sequence[str], **kw) -> D
     cer.update([pred[i] for i in idx], [truths[i] for i in idx])
     wer.update([pred[i] for i in idx], [truths[i] for i in idx])
     return {'cer': cer.compute(), 'wer': wer.compute(), 'chars': cer.total, 'lines': len(idx)}
+
+
+def validate(net, lines: Sequence[np.ndarray], truths: Sequence[str], batch_size: int = 32, edge: int = 200, rank: int = 0, world: int = 1,
+             device: str = 'cuda:0') -> Dict[str, float]:
+    """The reference's validation epoch (model.py:154-193): per batch `_step` (forward + CTC loss), greedy decode of the same
+    probits, CER / WER against the targets decoded back through the codec, `val_loss` = mean over batches of the summed loss
+    (torchmetrics MeanMetric over `o['loss']`).  The loss, the argmax and the run merging all stay on the device; only label
+    records and one float per line come back.  Lines whose text the codec cannot encode completely contribute what it encodes
+    (kraken's non-strict codec drops unknown characters)."""
+    from .ctc_decoder import GreedyDecoder
+    if not isinstance(net.ctc_decoder, GreedyDecoder):
+        raise ValueError('validation decodes greedily (model.py:163)')
+    batches = make_batches([l.shape[1] for l in lines], batch_size, edge)
+    cer, wer = ErrorRate(False), ErrorRate(True)
+    losses: List[torch.Tensor] = []
+    dev = torch.device(device)
+    pending = None
+
+    def finish(p):
+        idx, handle, labels = p
+        preds = [''.join(x[0] for x in net.codec.decode(locs)) for locs in net._engine.collect(handle)]
+        refs = [''.join(x[0] for x in net.codec.decode([(l, 0, 0, 0) for l in lab])) for lab in labels]       # model.py:166-171
+        cer.update(preds, refs)
+        wer.update(preds, refs)
+
+    for b in shard_batches(len(batches), rank, world):
+        width, idx = batches[b]
+        im, lens = collate(lines, idx, width)
+        labels = [net.codec.encode(truths[i]) for i in idx]
+        o = net.step({'image': im.to(dev), 'seq_lens': lens, 'target': np.array([l for lab in labels for l in lab], dtype=np.int64),
+                      'target_lens': np.array([len(lab) for lab in labels], dtype=np.int64)})
+        handle = net._engine.ctc_greedy_async(o['probits'], o['output_lens'].numpy())
+        losses.append(o['loss'])
+        if pending is not None:
+            finish(pending)
+        pending = (idx, handle, labels)
+    if pending is not None:
+        finish(pending)
+    val_loss = float(torch.stack(losses).mean().item()) if losses else 0.0
+    return {'cer': cer.compute(), 'wer': wer.compute(), 'val_loss': val_loss, 'val_accuracy': 1.0 - cer.compute(),
+            'val_word_accuracy': 1.0 - wer.compute(), 'chars': cer.total, 'batches': len(losses)}

@@ -203,6 +203,22 @@ class PytorchRecognitionModel(nn.Module):
         records = self._engine.collect(h) if kind == 'device' else h
         return [''.join(x[0] for x in self.codec.decode(locs)) for locs in records]
 
+    def step(self, batch: Dict, with_grad: bool = False) -> Dict:
+        """The reference's `RecognitionModel._step` (model.py:129-145) on a batch dict {'image' (N,1,H,W), 'seq_lens' (N),
+        'target' (sum target_lens,) concatenated labels, 'target_lens' (N)}: forward, then the criterion
+        `nn.CTCLoss(reduction='sum', zero_infinity=True)` on `log_softmax(probits)` -- on the device, without materialising the
+        log-probabilities.  Returns {'loss' (0-dim device tensor), 'probits', 'output_lens'} like the reference, plus 'nll'
+        (per-line terms of the sum) and, with_grad, 'grad_probits' = d loss / d probits: what autograd hands to the decoder's
+        backward in `training_step` (model.py:147-152).  Eval-mode forward (BatchNorm running statistics, no dropout): this is the
+        reference's `validation_step` forward (model.py:154-156); the encoder's backward is not part of this library yet."""
+        probits, out_lens = self.forward(batch['image'], batch['seq_lens'])
+        nll, grad = self._engine.ctc_loss(probits, out_lens.numpy(), torch.as_tensor(batch['target']).cpu().numpy(),
+                                          torch.as_tensor(batch['target_lens']).cpu().numpy(), with_grad=with_grad)
+        out = {'loss': nll.sum(), 'probits': probits, 'output_lens': out_lens, 'nll': nll}
+        if with_grad:
+            out['grad_probits'] = grad
+        return out
+
     def predict_labels(self, line: torch.tensor, lens: torch.Tensor = None) -> List[List[Tuple[int, int, int, float]]]:
         """
         Forward pass on a (N, C, H, W) batch; returns per line a list of tuples

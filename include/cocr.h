@@ -126,6 +126,17 @@ int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, int ncls, co
                   int32_t *labels, int32_t *starts, int32_t *ends, float *conf, int32_t *counts,
                   int max_per_line, int beam, void *stream);
 
+/* The loss of the reference's training / validation step, RecognitionModel._step (model.py:119,136-142):
+ *     nn.CTCLoss(reduction='sum', zero_infinity=True)(log_softmax(probits, -1).transpose(0, 1), target, encoder_lens, label_lens)
+ * and its gradient with respect to `probits` (what autograd hands to the decoder's backward).  probits DEVICE float32 (N,T,ncls), the
+ * output of cocr_forward; out_lens HOST (N) valid frames; targets HOST int32, the batch's labels concatenated (the reference's 1-D
+ * `target`), label_lens HOST (N); blank = 0, labels in [1, ncls), at most 255 per line.  nll (N) float32, DEVICE or pinned host:
+ * per-line negative log-likelihoods, 0 where no alignment exists (zero_infinity) -- the reference's scalar is their plain sum.
+ * grad (N,T,ncls) DEVICE float32 or NULL (validation: loss only): d sum(nll) / d probits, zero for frames >= out_lens[n].
+ * Deterministic (no floating-point atomics).  Stream-ordered, does not synchronise (workspace growth does). */
+int cocr_ctc_loss(cocr_model *m, const float *probits, int N, int T, int ncls, const int32_t *out_lens, const int32_t *targets,
+                  const int32_t *label_lens, float *nll, float *grad, void *stream);
+
 /* Line pre-processing in front of the path -- the step the reference delegates to kraken's
  * ImageInputTransforms(1, 96, 0, 1, (16, 0), valid_norm=False) (reference dataset.py:89, cli/test.py:156): grayscale, scale to
  * height `out_h` keeping the aspect ratio (Pillow's 8-bit LANCZOS resampler, bit for bit), `pad` zero columns left and right,

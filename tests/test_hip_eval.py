@@ -73,3 +73,34 @@ def test_recognize_from_raw_crops(case):
     got = recognize_crops(net, crops, batch_size=4)
     lines = [P.preprocess_line(c, hp.height, 16).astype(np.float32) / 255.0 for c in crops]
     assert got == recognize(net, lines, batch_size=4)
+
+
+def test_validation_step_loss_and_metrics(case):
+    """`net.step` = the reference's `_step` (forward + CTC criterion): the loss equals the CPU restatement's on the probits the
+    forward returned; `validate` reports the reference's validation-epoch numbers (CER / WER of greedy strings, mean batch loss)."""
+    from conformer_ocr_amd.evaluate import validate
+    from oracle import ctc_loss_ref as R
+    hp, state, image, lens, _ = case('cfg1')
+    net = _net(hp, state, 'fp32')
+    g = np.random.default_rng(3)
+    N = image.shape[0]
+    label_lens = g.integers(0, 12, size=N)
+    target = np.concatenate([g.integers(1, hp.num_classes, size=l) for l in label_lens] + [np.zeros(0, np.int64)])
+    o = net.step({'image': torch.from_numpy(image).cuda(), 'seq_lens': torch.from_numpy(lens), 'target': torch.from_numpy(target),
+                  'target_lens': torch.from_numpy(label_lens)}, with_grad=True)
+    probits = o['probits'].cpu().numpy()
+    want_nll, want_grad = R.ctc_loss(probits, target, o['output_lens'].numpy(), label_lens)
+    np.testing.assert_allclose(o['nll'].cpu().numpy(), want_nll, rtol=2e-6, atol=1e-3)
+    assert abs(float(o['loss']) - want_nll.sum()) < 2e-6 * want_nll.sum() + 1e-3
+    np.testing.assert_allclose(o['grad_probits'].cpu().numpy(), want_grad, atol=2e-3)
+    # validation epoch on mixed widths: the truths are the model's own strings, except two lines edited by hand
+    widths = [int(w) for w in g.integers(25, 80, size=12) * 8]
+    lines = [synth.make_lines(1, hp.height, w, seed=700 + i)[0][0, 0] for i, w in enumerate(widths)]
+    own = recognize(net, lines, batch_size=4)
+    truths = [own[i] for i in range(12)]
+    rep = validate(net, lines, truths, batch_size=4)
+    assert rep['cer'] == 0.0 and rep['val_accuracy'] == 1.0 and rep['batches'] >= 3 and rep['val_loss'] > 0
+    truths[0] = truths[0][1:]
+    truths[5] = truths[5] + 'xy'
+    rep2 = validate(net, lines, truths, batch_size=4)
+    assert abs(rep2['cer'] - 3 / rep2['chars']) < 1e-12 and rep2['val_loss'] != rep['val_loss']
