@@ -1,7 +1,8 @@
 // Relative-position multi-head self-attention core (reference conformer/attention.py:87-101 with
 // _relative_shift :105-113 and the positional slice of embedding.py:66), flash style:
 //
-//   score[b,h,i,j] = ((q_i + u_h) . k_j  +  (q_i + v_h) . P_h[CEN - (i - j)]) / sqrt(d_head)
+//   score[b,h,i,j] = ((q_i + u_h) . k_j  +  (q_i + v_h) . P_h[CEN - (i - j)]) / sqrt(d_head)      (`scale` = log2(e) / sqrt(d_head):
+//                                                                                                  scores in log2 units, 2^x softmax)
 //   ctx[b,i,h,:]   = sum_j softmax_j(score)[j] v_j          over ALL j in [0,T): no mask
 //
 // P is the per-layer table PE Wpos^T precomputed for all 9999 relative positions (row CEN = 4999 is
@@ -89,6 +90,15 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     auto stamp = [&]() {};
 #endif
     stamp();
+#ifdef COCR_CHAIN_STAMPS_BUILD
+    if (stamps && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamps[64 + 3 * logical] = wall_clock64();
+        stamps[64 + 3 * logical + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const T *kbase = k + (size_t)bh * Tp * DHP;
     const T *vbase = v + (size_t)bh * Tp * DHP;
     const int prow = heads * DHP;
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
-            const size_t off = (size_t)min(j0 + row, Tn - 1) * DHP + ch * (16 / (int)sizeof(T));
+            const unsigned off = (unsigned)min(j0 + row, Tn - 1) * DHP + ch * (16 / (int)sizeof(T));      // 32-bit offset from a uniform base
             rk[it] = *reinterpret_cast<const u32x4 *>(kbase + off);
             rv[it] = *reinterpret_cast<const u32x4 *>(vbase + off);
         }
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
         for (int it = 0; it < P_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
             const int pr = min(max(B0 + row, 0), COCR_POS_ROWS - 1);
-            rp[it] = *reinterpret_cast<const u32x4 *>(pbase + (size_t)pr * prow + ch * (16 / (int)sizeof(T)));
+            rp[it] = *reinterpret_cast<const u32x4 *>(pbase + ((unsigned)pr * (unsigned)prow + ch * (16 / (int)sizeof(T))));
         }
     };
     auto store_tile = [&]() {
@@ -234,12 +244,23 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int jl = 16 * tt + 4 * g + r;
-                    float sv = sc[tt][r] + sk[(15 - il + jl) * SK + il];
-                    if (tail) sv = (js + jl < Tn) ? sv : -INFINITY;
+                    const float sv = sc[tt][r] + sk[(15 - il + jl) * SK + il];
                     sc[tt][r] = sv;
                     tmax = fmaxf(tmax, sv);
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next sub-tile overwrites the shift tile
+            if (tail) {
+                // a real branch (the asm statement keeps the compiler from turning it into 4 selects per score in EVERY sub-tile)
+                asm volatile("; keys beyond the line" ::: "memory");
+                tmax = -INFINITY;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (js + 16 * tt + 4 * g + r >= Tn) sc[tt][r] = -INFINITY;
+                        tmax = fmaxf(tmax, sc[tt][r]);
+                    }
+            }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             // Lazy rescaling: the running reference m_run is only raised when some query of the wave exceeds it by more than
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                 m_run = tmax;                                     // finite: key 0 is valid
             } else if (__builtin_amdgcn_ballot_w64(tmax > m_run + LAZY) != 0) {
                 const float m_new = fmaxf(m_run, tmax);
-                const float alpha = __expf(m_run - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 m_run = m_new;
                 l_run *= alpha;
 #pragma unroll
@@ -264,7 +285,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(sc[tt][r] - m_run);
+                    const float p = __builtin_amdgcn_exp2f(sc[tt][r] - m_run);       // scores are in log2 units (see `scale`)
                     psum += p;
                     pb[4 * tt + r] = from_f32<T>(p);
                 }
@@ -276,6 +297,9 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
         }
     }
     stamp();
+#ifdef COCR_CHAIN_STAMPS_BUILD
+    if (stamps && tid == 0) stamps[64 + 3 * logical + 1] = wall_clock64();
+#endif
     // ---- normalise and store: lane holds head dims 16 d + 4g + r of query i0 + il
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);

@@ -183,7 +183,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_FRONT96"); m->no_front96 = e && e[0] == '1'; }
     { const char *e = getenv("COCR_BEAM_REF"); m->beam_ref = e && e[0] == '1'; }
-    { const char *e = getenv("COCR_CHAIN_STAMPS"); if (e && e[0] == '1') { (void)hipHostMalloc((void **)&m->stamps, 256 * 8); memset(m->stamps, 0, 256 * 8); } }
+    { const char *e = getenv("COCR_CHAIN_STAMPS"); if (e && e[0] == '1') { (void)hipHostMalloc((void **)&m->stamps, 4096 * 8); memset(m->stamps, 0, 4096 * 8); } }
     int f = hp->height;
     for (int i = 0; i < snum; ++i) { f = out_len1(f); m->feats.push_back(f); }
     // expected state-dict entries, reference key names
@@ -256,6 +256,32 @@ extern "C" void cocr_destroy(cocr_model *m) {
         fprintf(stderr, "\nattention stamps:");
         for (int i = 193; i < 240 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[192]);
         fprintf(stderr, "\n");
+        {   // per-workgroup (start, end, hardware id) of the stamped attention launch: residency and tail
+            const unsigned long long *w = m->stamps + 192 + 64;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            int nwg = 0;
+            for (int i = 0; i < 1200 && w[3 * i]; ++i) { t0 = std::min(t0, w[3 * i]); t1 = std::max(t1, w[3 * i + 1]); nwg = i + 1; }
+            if (nwg) {
+                fprintf(stderr, "attention workgroups %d, span %.2f us (100 MHz ticks)\n", nwg, (t1 - t0) * 0.01);
+                std::map<unsigned long long, int> per_cu;
+                int hist_start[32] = {0};
+                double dur = 0;
+                for (int i = 0; i < nwg; ++i) {
+                    const unsigned long long hw = w[3 * i + 2];
+                    const unsigned long long cu = ((hw >> 32) << 16) | ((hw >> 8) & 0xff) | (((hw >> 13) & 7) << 8);
+                    per_cu[cu]++;
+                    hist_start[std::min<unsigned long long>((w[3 * i] - t0) / 100, 31)]++;
+                    dur += (w[3 * i + 1] - w[3 * i]) * 0.01;
+                }
+                fprintf(stderr, "  mean workgroup duration %.2f us; distinct CUs %zu; start-time histogram (1 us bins):", dur / nwg, per_cu.size());
+                for (int b = 0; b < 32; ++b) fprintf(stderr, " %d", hist_start[b]);
+                int cnt[8] = {0};
+                for (auto &kv : per_cu) cnt[std::min(kv.second, 7)]++;
+                fprintf(stderr, "\n  CUs by number of workgroups received (0..7+):");
+                for (int b = 0; b < 8; ++b) fprintf(stderr, " %d", cnt[b]);
+                fprintf(stderr, "\n");
+            }
+        }
         (void)hipHostFree(m->stamps);
     }
     if (m->d_lens) (void)hipFree(m->d_lens);
@@ -686,7 +712,9 @@ static hipError_t launch_attention(hipStream_t s, dim3 grid, const T *q, const T
     auto kern = relpos_attention_kernel<T, DHP>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh, scale, stamps);
+    // log2(e) rides on the 1/sqrt(d_head) factor folded into the query operands: the kernel's scores are in log2 units and its
+    // softmax uses v_exp_f32 (2^x) directly -- one multiply per score less
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh, scale * 1.44269504088896340736f, stamps);
     return hipGetLastError();
 }
 
