@@ -22,6 +22,7 @@
 #include "conv.hip.h"
 #include "ctc.hip.h"
 #include "ctc_loss.hip.h"
+#include "train.hip.h"
 #include "gemm.hip.h"
 #include "ffn.hip.h"
 #include "chain.hip.h"
@@ -116,6 +117,11 @@ struct cocr_model {
     int loss_slot = 0;
     float *loss_ws = nullptr;                          // log-softmax + alpha / beta tables
     size_t loss_ws_cap = 0;
+    int lastN = 0, lastT = 0;                          // shape of the last forward: its encoder output is still in `xn`
+    float *tr_part = nullptr;                          // decoder backward: per-chunk partial sums of dW | db
+    size_t tr_part_cap = 0;
+    float *tr_state = nullptr;                         // decoder AdamW: fp32 master [W | b], then exp_avg, then exp_avg_sq
+    long tr_step = 0;
     // debug / profile
     // hipGraph replay of the forward's launch sequence, keyed by the call's shapes and buffers
     bool use_graph = false;
@@ -292,6 +298,8 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->loss_d) (void)hipFree(m->loss_d);
     if (m->loss_h) (void)hipHostFree(m->loss_h);
     if (m->loss_ws) (void)hipFree(m->loss_ws);
+    if (m->tr_part) (void)hipFree(m->tr_part);
+    if (m->tr_state) (void)hipFree(m->tr_state);
     for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
@@ -407,6 +415,7 @@ static int alloc_blob(cocr_model *m, int dtype) {
     if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
     if (m->packed) { (void)hipFree(m->packed); m->packed = nullptr; }
     if (m->fpack) { (void)hipFree(m->fpack); m->fpack = nullptr; }
+    if (m->tr_state) { (void)hipFree(m->tr_state); m->tr_state = nullptr; m->tr_step = 0; }      // optimizer state belongs to the old weights
     m->packed_stale = true;
     m->plan = make_plan(m, dtype);
     m->dtype = dtype;
@@ -449,6 +458,7 @@ extern "C" int cocr_blob_import(cocr_model *m, const void *src_device, size_t by
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(m->blob, src_device, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     m->packed_stale = true;
+    if (m->tr_state) { (void)hipFree(m->tr_state); m->tr_state = nullptr; m->tr_step = 0; }
     return COCR_OK;
 }
 
@@ -1047,6 +1057,8 @@ extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, in
         for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
     hipStream_t s = (hipStream_t)stream;
     if ((rc = ensure_packed(m, s))) return rc;
+    m->lastN = N;
+    m->lastT = cocr_out_len(W, m->hp.subsampling_factor);
     auto run = [&]() -> int {
         if (m->dtype == COCR_BF16) {
             if (line_dtype == COCR_F32) return forward_impl<bf16_t, float>(m, (const float *)lines, N, H, W, logits, s);
@@ -1222,6 +1234,99 @@ extern "C" int cocr_ctc_loss(cocr_model *m, const float *probits, int N, int T, 
     ProfScope ps(m, s, FAM_LOSS);
     launch_ctc_loss(s, sj, (size_t)ncls * 4, probits, N, T, ncls, d, d + N, d + 2 * N, d + 3 * N, nll, grad, m->loss_ws, m->loss_ws + (size_t)N * T * ncls);
     LAUNCH_CHECK();
+    return COCR_OK;
+}
+
+// ------------------------------------------------------------------------------------ output-layer training step (train.hip.h)
+extern "C" int cocr_decoder_backward(cocr_model *m, const float *grad_probits, int N, int T, float *grad_weight, float *grad_bias, float *grad_output,
+                                     void *stream) {
+    if (!m || !grad_probits || !grad_weight || !grad_bias) return fail(COCR_EINVAL, "null argument");
+    if (m->dtype < 0 || !m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (N != m->lastN || T != m->lastT || !m->xn) return fail(COCR_ESTATE, "no forward of shape (%d lines, %d frames) precedes this call (last forward: %d, %d)", N, T, m->lastN, m->lastT);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int M = N * T, C = m->ncls, D = m->D, chunks = ceil_div(M, COCR_TR_ROWS);
+    const size_t per = (size_t)C * D + C, need = per * chunks;
+    if (need > m->tr_part_cap) {
+        if (m->tr_part) (void)hipFree(m->tr_part);
+        m->tr_part = nullptr;
+        m->tr_part_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m->tr_part, need * 4));
+        m->tr_part_cap = need;
+    }
+    float *part_w = m->tr_part, *part_b = m->tr_part + (size_t)chunks * C * D;
+    const dim3 grid(chunks, ceil_div(C, COCR_TR_CT));
+    if (m->dtype == COCR_BF16) hipLaunchKernelGGL((decoder_wgrad_kernel<bf16_t>), grid, dim3(256), 0, s, grad_probits, (const bf16_t *)m->xn, M, C, D, part_w, part_b);
+    else hipLaunchKernelGGL((decoder_wgrad_kernel<float>), grid, dim3(256), 0, s, grad_probits, (const float *)m->xn, M, C, D, part_w, part_b);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3(ceil_div(C * D, 256)), dim3(256), 0, s, part_w, chunks, (size_t)C * D, grad_weight);
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, part_b, chunks, (size_t)C, grad_bias);
+    LAUNCH_CHECK();
+    if (grad_output) {
+        if (m->dtype == COCR_BF16) hipLaunchKernelGGL((decoder_igrad_kernel<bf16_t>), dim3(ceil_div(M, 16)), dim3(256), 0, s, grad_probits, (const bf16_t *)(m->blob + m->plan.wdec), M, C, D, grad_output);
+        else hipLaunchKernelGGL((decoder_igrad_kernel<float>), dim3(ceil_div(M, 16)), dim3(256), 0, s, grad_probits, (const float *)(m->blob + m->plan.wdec), M, C, D, grad_output);
+        LAUNCH_CHECK();
+    }
+    return COCR_OK;
+}
+
+extern "C" int cocr_decoder_adamw(cocr_model *m, const float *grad_weight, const float *grad_bias, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, void *stream) {
+    if (!m || !grad_weight || !grad_bias) return fail(COCR_EINVAL, "null argument");
+    if (m->dtype < 0 || !m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f) || !(weight_decay >= 0.f))
+        return fail(COCR_EINVAL, "invalid AdamW hyper-parameters");            // torch.optim.AdamW's own checks
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nw = (size_t)m->ncls * m->D, nb = (size_t)m->ncls, n = nw + nb;
+    if (!m->tr_state) {
+        // fp32 master copy: the state-dict tensors when this rank has them, else (weights received by broadcast) the blob's values
+        HIP_TRY(hipMalloc((void **)&m->tr_state, 3 * n * 4));
+        HIP_TRY(hipMemsetAsync(m->tr_state + n, 0, 2 * n * 4, s));
+        auto w = m->host.find("decoder.weight"), b = m->host.find("decoder.bias");
+        if (w != m->host.end() && w->second.set && w->second.data.size() == nw && b != m->host.end() && b->second.set && b->second.data.size() == nb) {
+            HIP_TRY(hipMemcpyAsync(m->tr_state, w->second.data.data(), nw * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(m->tr_state + nw, b->second.data.data(), nb * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));                                   // pageable sources
+        } else {
+            if (m->dtype == COCR_BF16) hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(64), dim3(256), 0, s, (const bf16_t *)(m->blob + m->plan.wdec), m->tr_state, nw);
+            else hipLaunchKernelGGL((to_f32_kernel<float>), dim3(64), dim3(256), 0, s, (const float *)(m->blob + m->plan.wdec), m->tr_state, nw);
+            HIP_TRY(hipMemcpyAsync(m->tr_state + nw, m->blob + m->plan.bdec, nb * 4, hipMemcpyDeviceToDevice, s));
+            LAUNCH_CHECK();
+        }
+        m->tr_step = 0;
+    }
+    const long t = ++m->tr_step;
+    const float bc1 = 1.0f - (float)pow((double)beta1, (double)t), bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    float *p = m->tr_state, *m1 = p + n, *m2 = m1 + n;
+    if (m->dtype == COCR_BF16)
+        hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(ceil_div((int)nw, 256)), dim3(256), 0, s, p, grad_weight, m1, m2, nw, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                           (bf16_t *)(m->blob + m->plan.wdec), (float *)nullptr);
+    else
+        hipLaunchKernelGGL((adamw_kernel<float>), dim3(ceil_div((int)nw, 256)), dim3(256), 0, s, p, grad_weight, m1, m2, nw, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                           (float *)nullptr, (float *)(m->blob + m->plan.wdec));
+    hipLaunchKernelGGL((adamw_kernel<float>), dim3(ceil_div((int)nb, 256)), dim3(256), 0, s, p + nw, grad_bias, m1 + nw, m2 + nw, nb, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                       (float *)nullptr, (float *)(m->blob + m->plan.bdec));
+    LAUNCH_CHECK();
+    return COCR_OK;
+}
+
+extern "C" int cocr_get_tensor(cocr_model *m, const char *name, float *host_out, int64_t max_elems, void *stream) {
+    if (!m || !name || !host_out) return fail(COCR_EINVAL, "null argument");
+    const bool is_w = !strcmp(name, "decoder.weight"), is_b = !strcmp(name, "decoder.bias");
+    if (!is_w && !is_b) return fail(COCR_EINVAL, "only decoder.weight / decoder.bias are trained by this library (got '%s')", name);
+    const size_t nw = (size_t)m->ncls * m->D, nb = (size_t)m->ncls, n = is_w ? nw : nb;
+    if ((int64_t)n > max_elems) return fail(COCR_EINVAL, "%s has %zu elements, buffer %lld", name, n, (long long)max_elems);
+    auto it = m->host.find(name);
+    if (m->tr_state) {
+        HIP_TRY(hipSetDevice(m->device));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(host_out, m->tr_state + (is_w ? 0 : nw), n * 4, hipMemcpyDeviceToHost));
+        if (it != m->host.end() && it->second.data.size() == n) memcpy(it->second.data.data(), host_out, n * 4);      // a later cocr_finalize keeps the trained values
+        return COCR_OK;
+    }
+    if (it == m->host.end() || !it->second.set || it->second.data.size() != n) return fail(COCR_ESTATE, "%s was never set on this model", name);
+    memcpy(host_out, it->second.data.data(), n * 4);
     return COCR_OK;
 }
 

@@ -224,6 +224,48 @@ class HipRecognizer:
                                               _stream_ptr(self.device)))
         return nll, grad
 
+    # ---- output-layer training step (include/cocr.h: cocr_decoder_backward / cocr_decoder_adamw) ----------
+    def decoder_backward(self, grad_probits: torch.Tensor, with_input_grad: bool = False):
+        """Gradients of the decoder `nn.Linear` for the LAST forward on this engine: (grad_weight (ncls, D), grad_bias (ncls),
+        grad_output (N, T, D) or None), float32 device tensors."""
+        if grad_probits.device != self.device or grad_probits.dtype != torch.float32 or grad_probits.dim() != 3:
+            raise RuntimeError('grad_probits must be a float32 (N,T,num_classes) tensor on the model device')
+        grad_probits = grad_probits.contiguous()
+        N, T, ncls = grad_probits.shape
+        if ncls != self.hp.num_classes:
+            raise ValueError('grad_probits has the wrong number of classes')
+        D = self.hp.encoder_dim
+        gw = torch.empty((ncls, D), dtype=torch.float32, device=self.device)
+        gb = torch.empty((ncls,), dtype=torch.float32, device=self.device)
+        gy = torch.empty((N, T, D), dtype=torch.float32, device=self.device) if with_input_grad else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_decoder_backward(self._h, C.c_void_p(grad_probits.data_ptr()), N, T, C.c_void_p(gw.data_ptr()),
+                                                      C.c_void_p(gb.data_ptr()), C.c_void_p(gy.data_ptr()) if with_input_grad else None,
+                                                      _stream_ptr(self.device)))
+        return gw, gb, gy
+
+    def decoder_adamw(self, grad_weight: torch.Tensor, grad_bias: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                      weight_decay: float = 1e-2) -> None:
+        """One torch.optim.AdamW step on the decoder (state kept inside the engine); defaults are torch's."""
+        for g in (grad_weight, grad_bias):
+            if g.device != self.device or g.dtype != torch.float32 or not g.is_contiguous():
+                raise RuntimeError('gradients must be contiguous float32 tensors on the model device')
+        if grad_weight.shape != (self.hp.num_classes, self.hp.encoder_dim) or grad_bias.shape != (self.hp.num_classes,):
+            raise ValueError('gradient shapes do not match the decoder')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_decoder_adamw(self._h, C.c_void_p(grad_weight.data_ptr()), C.c_void_p(grad_bias.data_ptr()), float(lr),
+                                                   float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _stream_ptr(self.device)))
+
+    def decoder_state(self) -> Dict[str, np.ndarray]:
+        """{'decoder.weight', 'decoder.bias'}: float32 host copies of the (trained) output layer."""
+        out = {}
+        for name, shape in (('decoder.weight', (self.hp.num_classes, self.hp.encoder_dim)), ('decoder.bias', (self.hp.num_classes,))):
+            a = np.empty(shape, dtype=np.float32)
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.cocr_get_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size, _stream_ptr(self.device)))
+            out[name] = a
+        return out
+
     # ---- line pre-processing (include/cocr.h: cocr_preproc_lines) --------------------------------------
     def preprocess(self, lines: Sequence[np.ndarray], height: Optional[int] = None, pad: int = 16, width: int = 0,
                    bucket_edge: int = 0) -> Tuple[torch.Tensor, np.ndarray]:

@@ -137,6 +137,27 @@ int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, int ncls, co
 int cocr_ctc_loss(cocr_model *m, const float *probits, int N, int T, int ncls, const int32_t *out_lens, const int32_t *targets,
                   const int32_t *label_lens, float *nll, float *grad, void *stream);
 
+/* Training step of the output layer: the part of the reference's `training_step` (model.py:147-152, autograd through
+ * `nn['decoder'] = nn.Linear(encoder_dim, num_classes)`, model.py:115) between the encoder output and the criterion, and the
+ * reference's default optimizer (`torch.optim.AdamW`, model.py:47,283-284).  The encoder's backward is not in this library yet;
+ * with these calls the output layer trains on a frozen backbone (`freeze_backbone`, default_specs.py:47).
+ * cocr_decoder_backward: grad_probits DEVICE float32 (N,T,ncls) = d loss / d probits (cocr_ctc_loss) for the LAST cocr_forward on this
+ * model (N, T must match it: the encoder output it multiplied is still in the workspace) ->
+ *   grad_weight (ncls, encoder_dim), grad_bias (ncls): DEVICE float32, the `.grad` of decoder.weight / decoder.bias;
+ *   grad_output (N,T,encoder_dim) DEVICE float32 or NULL: d loss / d encoder output (what the encoder's backward would receive).
+ * Deterministic (fixed-order reductions).  Stream-ordered.
+ * cocr_decoder_adamw: one torch.optim.AdamW step (decoupled weight decay, no amsgrad) on decoder.weight / decoder.bias with the given
+ * gradients (after the caller's all-reduce across ranks, if any); keeps an fp32 master copy and the two moment buffers inside the
+ * model (created on the first call: step counter 1), and writes the updated values where the next cocr_forward reads them.
+ * cocr_finalize / cocr_blob_import discard that state.
+ * cocr_get_tensor: decoder.weight / decoder.bias as float32 into HOST memory (the trained master copy if training has started, else
+ * the tensor given to cocr_set_tensor) -- for writing checkpoints.  Synchronises `stream`. */
+int cocr_decoder_backward(cocr_model *m, const float *grad_probits, int N, int T, float *grad_weight, float *grad_bias, float *grad_output,
+                          void *stream);
+int cocr_decoder_adamw(cocr_model *m, const float *grad_weight, const float *grad_bias, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, void *stream);
+int cocr_get_tensor(cocr_model *m, const char *name, float *host_out, int64_t max_elems, void *stream);
+
 /* Line pre-processing in front of the path -- the step the reference delegates to kraken's
  * ImageInputTransforms(1, 96, 0, 1, (16, 0), valid_norm=False) (reference dataset.py:89, cli/test.py:156): grayscale, scale to
  * height `out_h` keeping the aspect ratio (Pillow's 8-bit LANCZOS resampler, bit for bit), `pad` zero columns left and right,

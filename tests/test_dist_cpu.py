@@ -80,3 +80,40 @@ def test_evaluation_helpers():
     lines = [np.full((4, w), 0.5, np.float32) for w in (5, 3)]
     im, lens = collate(lines, [0, 1], 8)
     assert im.shape == (2, 1, 4, 8) and lens.tolist() == [5, 3] and float(im[1, 0, 0, 3]) == 0.0
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from conformer_ocr_amd.train import reduce_gradients
+        g = torch.Generator().manual_seed(100 + rank)
+        gw, gb = torch.randn((7, 16), generator=g), torch.randn((7,), generator=g)
+        reduce_gradients((gw, gb))
+        q.put((rank, gw.numpy(), gb.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world_size_2_gradient_all_reduce():
+    """Data-parallel output-layer training (conformer_ocr_amd/train.py): the two decoder gradients are SUMMED over ranks in one
+    flat bucket (the reference's loss is a sum over lines), every rank ends with the same tensors."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=100) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want_w = sum(torch.randn((7, 16), generator=torch.Generator().manual_seed(100 + r)) for r in range(2)).numpy()
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
+    ws = [torch.randn((7, 16), generator=g) for g in gens]
+    bs = [torch.randn((7,), generator=g) for g in gens]
+    np.testing.assert_allclose(res[0][1], (ws[0] + ws[1]).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(res[0][2], (bs[0] + bs[1]).numpy(), rtol=1e-6)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and want_w.shape == (7, 16)
