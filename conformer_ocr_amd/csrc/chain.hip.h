@@ -505,13 +505,18 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     auto step = [&](const unsigned char *img, f32x4 (&acc)[MT][2], const T *nxt, auto &&side) {
 #pragma unroll
         for (int kk = 0; kk < KC1; ++kk) {
-            bf16x8 a[MT];
+            // row tiles in two halves: 12 operand registers live instead of 24 (the 96-row FFN stage is at the 256-register limit)
+            constexpr int HT = MT > 3 ? MT / 2 : MT;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = lds_frag_swz(img + (kk >> 1) * PANEL + (16 * i + r16) * 128, kk & 1, g, swz, T());
+            for (int h0 = 0; h0 < MT; h0 += HT) {
+                bf16x8 a[HT];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < HT; ++i) a[i] = lds_frag_swz(img + (kk >> 1) * PANEL + (16 * (h0 + i) + r16) * 128, kk & 1, g, swz, T());
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i][j] = mma16(ring[2 * kk + j], a[i], acc[i][j]);
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < HT; ++i) acc[h0 + i][j] = mma16(ring[2 * kk + j], a[i], acc[h0 + i][j]);
+            }
             fill(nxt, 2 * kk);
             fill(nxt, 2 * kk + 1);
             side(std::integral_constant<int, 0>{}, kk);
@@ -568,25 +573,36 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     //   chained: x <- LN1(x + staged) ;  xn <- LN2(x)          (block-final LayerNorm + the next block's first)
     // The 12 residual rows of this wave's share of the LayerNorm epilogue.  Requested BEFORE the stage's last product step (its
     // 16 ring refills are then younger: the epilogue waits for these loads only, and their ~2 us of latency pass under the step).
-    struct Resid { f32x4 v[LNP][4]; };
+    // The last pass's rows are requested at the START of the epilogue instead (LATE = 1 at 96 rows): 16 registers less across the
+    // product step (the 96-row FFN form sits at the 256-register limit; together with the halved operand fragments in `step` the
+    // dominant kernel's scratch went 64 -> 36 bytes per lane; time unchanged within the +-2 us run-to-run noise).
+    constexpr int LATE = LNP >= 3 ? 1 : 0, EARLY = LNP - LATE;
+    struct Resid { f32x4 v[EARLY][4]; };
+    auto resid_row = [&](const ChainStage &st, int pass, f32x4 (&out)[4]) {
+        const int rl = lane >> 4, cl = lane & 15;
+        const int m = min(m0 + (BMC / 8) * wave + 4 * pass + rl, mend - 1);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            out[v] = st.has_resid ? *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
     auto load_resid = [&](const ChainStage &st) {
         Resid r;
-        const int rl = lane >> 4, cl = lane & 15;
 #pragma unroll
-        for (int pass = 0; pass < LNP; ++pass) {
-            const int m = min(m0 + (BMC / 8) * wave + 4 * pass + rl, mend - 1);
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                r.v[pass][v] = st.has_resid ? *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int pass = 0; pass < EARLY; ++pass) resid_row(st, pass, r.v[pass]);
         return r;
     };
     auto rowln_epilogue = [&](const ChainStage &st, const Resid &res) {
         const int rl = lane >> 4, cl = lane & 15;
         const bool chained = st.g2 != nullptr;
-        const f32x4 (&xr)[LNP][4] = res.v;
         if (wave < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // this stage's LayerNorm parameters have landed
         lds_fence_barrier();                                 // staged tile complete; every wave is done reading the old image
+        f32x4 xr[LNP][4];
+#pragma unroll
+        for (int pass = 0; pass < EARLY; ++pass)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xr[pass][v] = res.v[pass][v];
+#pragma unroll
+        for (int pass = EARLY; pass < LNP; ++pass) resid_row(st, pass, xr[pass]);
         constexpr float inv_d = 1.0f / (float)D;
         auto normalise = [&](f32x4 (&t)[4], int which) {     // which: 0 = (g1, b1), 1 = (g2, b2)
             const float *ga = lnp + which * 512, *be = ga + 256;
