@@ -35,16 +35,22 @@ __device__ __forceinline__ int xcd_remap_i(int bid, int nwg) {
 
 // V^T fragment of one k-chunk (32 keys) for head-dim row tile d: element e of quad g <-> key 16 (e>>2) + 4g + (e&3)
 // (the same permutation the exponentiated scores have in their accumulator registers).
+template <bool SWZ>
 __device__ __forceinline__ bf16x8 load_vt_frag(const unsigned char *vtile, int stride, int key0, int d, int il, int g, bf16_t) {
     // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a 4x16 block and
     // receives column (lane & 15) of the 4 rows.  Block rows = keys key0 + 4g + q, block columns = dims 16 d ..+15.
-    const unsigned char *p0 = vtile + (key0 + 4 * g + (il >> 2)) * stride + (16 * d + 4 * (il & 3)) * 2;
+    // SWZ: 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7) (key0 is a multiple of 8; the second read is 16 rows on)
+    const int row = key0 + 4 * g + (il >> 2);
+    const unsigned char *p0 = SWZ ? vtile + row * stride + (((2 * d + ((il & 3) >> 1)) ^ (row & 7)) << 4) + 8 * (il & 1)
+                                  : vtile + row * stride + (16 * d + 4 * (il & 3)) * 2;
     typedef __attribute__((address_space(3))) bf16x4 *lp;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)p0);
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p0 + 16 * stride));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+template <bool SWZ>
 __device__ __forceinline__ f32x8 load_vt_frag(const unsigned char *vtile, int stride, int key0, int d, int il, int g, float) {
+    static_assert(!SWZ, "the swizzled image is the bf16 / 128-byte-row form");
     f32x8 r;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -58,10 +64,16 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                                                                const float *__restrict__ vb, T *__restrict__ ctx,
                                                                int Tn, int Tp, int heads, int dh, float scale, unsigned long long *stamps) {
     constexpr int KC = DHP / 32;                      // k-chunks over the head dim
+    constexpr bool MERGE = sizeof(T) == 2 && DHP <= 64;   // one softmax step per 64 keys (bf16: the registers allow it at 3 waves per SIMD)
     constexpr int DT = DHP / 16;                      // 16-row tiles of O^T
     constexpr int SK = 20;                            // row stride (floats) of the shift tile: conflict-free write and skewed read
     constexpr int RB = DHP * (int)sizeof(T);          // bytes per operand row
-    constexpr int RS = RB + 16;                       // padded LDS row
+    // LDS rows: 128-byte rows (bf16, d_head 64: the measured configuration) are stored unpadded with the 16-byte chunk index
+    // XOR-ed with (row & 7): ds_read_b128 fragment reads, the ds_read_b64_tr_b16 reads of V and the staging ds_write_b128 are all
+    // bank-conflict free (with the former 144-byte padded rows 7 of 8 fragment reads were 2-way conflicts); other row sizes keep
+    // a 16-byte pad.
+    constexpr bool SWZ = RB == 128 && sizeof(T) == 2;
+    constexpr int RS = SWZ ? RB : RB + 16;
     constexpr int CPR = RB / 16;                      // 16-byte chunks per row
     constexpr int KV_IT = 64 * CPR / 256, P_IT = 128 * CPR / 256;
     typedef typename FragOf<T>::type frag_t;
@@ -71,6 +83,9 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int il = lane & 15, g = lane >> 4;
+    // byte offset of this lane's 16 (bf16) / 32 (fp32) bytes of k-chunk c inside a tile row whose index is il mod 8 (every
+    // fragment row base below is a multiple of 16 rows)
+    auto frag_off = [&](int c) { return SWZ ? (((4 * c + g) ^ (il & 7)) << 4) : (c * 32 + 8 * g) * (int)sizeof(T); };
     // XCD-aware order: the query tiles of one (line, head) re-read the same K / V / P rows; consecutive LOGICAL workgroups share
     // an XCD (hardware id % 8 picks the XCD), so those rows are fetched into one L2 instead of up to five
     // (PMC: 61 MB of HBM traffic per launch against 21 MB algorithmic with the plain (x, y) order).
@@ -127,13 +142,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
-            *reinterpret_cast<u32x4 *>(ks + row * RS + ch * 16) = rk[it];
-            *reinterpret_cast<u32x4 *>(vs + row * RS + ch * 16) = rv[it];
+            const int cs = SWZ ? (ch ^ (row & 7)) : ch;
+            *reinterpret_cast<u32x4 *>(ks + row * RS + cs * 16) = rk[it];
+            *reinterpret_cast<u32x4 *>(vs + row * RS + cs * 16) = rv[it];
         }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
-            *reinterpret_cast<u32x4 *>(ps + row * RS + ch * 16) = rp[it];
+            *reinterpret_cast<u32x4 *>(ps + row * RS + (SWZ ? (ch ^ (row & 7)) : ch) * 16) = rp[it];
         }
     };
     load_tile(0);
@@ -211,6 +227,90 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
         __syncthreads();
         stamp();
         load_tile(j0 + 64 < Tn ? j0 + 64 : j0);   // in flight during the compute below (unconditional: the staging registers stay registers)
+        if constexpr (MERGE) {
+            // ---- one softmax step per 64-key tile: the two 32-key halves still take the shift tile in turn (it holds 48 band rows),
+            // but the cross-lane maximum (two dependent ds_bpermute round trips), the rescale test, the exponentials and the P.V
+            // product run once per tile on 16 scores per lane -- the per-wave dependent chain is what bounds this kernel.
+            f32x4 sc[4];
+            f32x4 keep = {0.f, 0.f, 0.f, 0.f};                    // band tile 2: last of the first half, first of the second
+            const int lb0 = 48 - 16 * wave;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const int tt = 2 * half + tl;
+                    sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const unsigned char *kr = ks + (16 * tt + il) * RS;
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]);
+                }
+#pragma unroll
+                for (int ml = 0; ml < 3; ++ml) {
+                    f32x4 rr;
+                    if (half == 1 && ml == 0) rr = keep;
+                    else {
+                        rr = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        const unsigned char *pr = ps + (lb0 + 16 * (2 * half + ml) + il) * RS;
+#pragma unroll
+                        for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr + frag_off(c))), qv[c], rr);
+                    }
+                    if (half == 0 && ml == 2) keep = rr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sk[(16 * ml + 4 * g + r) * SK + il] = rr[r];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the shift tile is private to the wave; its LDS operations execute in order
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[2 * half + tl][r] += sk[(15 - il + 16 * tl + 4 * g + r) * SK + il];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the tile is overwritten
+            }
+            float tmax = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+            tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(sc[2][0], sc[2][1]), fmaxf(sc[2][2], sc[2][3])), fmaxf(fmaxf(sc[3][0], sc[3][1]), fmaxf(sc[3][2], sc[3][3]))));
+            if (j0 + 64 > Tn) {                                      // uniform: only the last tile has keys beyond T (a real branch, see below)
+                asm volatile("; keys beyond the line" ::: "memory");
+                tmax = -INFINITY;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (j0 + 16 * tt + 4 * g + r >= Tn) sc[tt][r] = -INFINITY;
+                        tmax = fmaxf(tmax, sc[tt][r]);
+                    }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            constexpr float LAZY = 8.0f;                             // lazy rescaling: see the 32-key form below
+            if (j0 == 0) {
+                m_run = tmax;
+            } else if (__builtin_amdgcn_ballot_w64(tmax > m_run + LAZY) != 0) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+            }
+            float psum = 0.f;
+            frag_t pb[2];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sc[tt][r] - m_run);
+                    psum += pv;
+                    pb[tt >> 1][4 * (tt & 1) + r] = from_f32<T>(pv);
+                }
+            l_run += psum;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                o[d] = mma16(load_vt_frag<SWZ>(vs, RS, 0, d, il, g, T()), pb[0], o[d]);
+                o[d] = mma16(load_vt_frag<SWZ>(vs, RS, 32, d, il, g, T()), pb[1], o[d]);
+            }
+            stamp();
+        } else {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int js = j0 + 32 * s2;       // first key of this 32-key sub-tile
@@ -222,7 +322,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                 sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const unsigned char *kr = ks + (32 * s2 + 16 * tt + il) * RS;
 #pragma unroll
-                for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr) + c * 32 + 8 * g), qu[c], sc[tt]);
+                for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]);
             }
             // ---- positional scores: band rows lb + 16 mt + il of the staged band, lb = (48 - 16 wave) + 32 s2
             const int lb = 48 - 16 * wave + 32 * s2;
@@ -231,7 +331,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                 f32x4 rr = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const unsigned char *pr = ps + (lb + 16 * mt + il) * RS;
 #pragma unroll
-                for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr) + c * 32 + 8 * g), qv[c], rr);
+                for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr + frag_off(c))), qv[c], rr);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sk[(16 * mt + 4 * g + r) * SK + il] = rr[r];
             }
@@ -292,8 +392,9 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             l_run += psum;
             // ---- O^T += V^T_sub . P^T
 #pragma unroll
-            for (int d = 0; d < DT; ++d) o[d] = mma16(load_vt_frag(vs, RS, 32 * s2, d, il, g, T()), pb, o[d]);
+            for (int d = 0; d < DT; ++d) o[d] = mma16(load_vt_frag<SWZ>(vs, RS, 32 * s2, d, il, g, T()), pb, o[d]);
             stamp();
+        }
         }
     }
     stamp();
@@ -323,5 +424,6 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 }
 
 template <typename T, int DHP> static inline size_t attention_lds_bytes() {
-    return (size_t)(64 + 64 + 128) * (DHP * sizeof(T) + 16) + 4 * 48 * 20 * sizeof(float);
+    const size_t rb = DHP * sizeof(T);
+    return (size_t)(64 + 64 + 128) * ((rb == 128 && sizeof(T) == 2) ? rb : rb + 16) + 4 * 48 * 20 * sizeof(float);
 }
