@@ -187,6 +187,23 @@ def validate(net, lines: Sequence[np.ndarray], truths: Sequence[str], batch_size
         pending = (idx, handle, labels)
     if pending is not None:
         finish(pending)
-    val_loss = float(torch.stack(losses).mean().item()) if losses else 0.0
+    loss_sum = float(torch.stack(losses).sum().item()) if losses else 0.0
+    counts = reduce_counts([cer.errors, cer.total, wer.errors, wer.total, loss_sum, len(losses)], dev if world > 1 else None)
+    cer.errors, cer.total, wer.errors, wer.total = int(counts[0]), int(counts[1]), int(counts[2]), int(counts[3])
+    val_loss = counts[4] / max(counts[5], 1.0)
     return {'cer': cer.compute(), 'wer': wer.compute(), 'val_loss': val_loss, 'val_accuracy': 1.0 - cer.compute(),
-            'val_word_accuracy': 1.0 - wer.compute(), 'chars': cer.total, 'batches': len(losses)}
+            'val_word_accuracy': 1.0 - wer.compute(), 'chars': cer.total, 'batches': int(counts[5])}
+
+
+def reduce_counts(values: Sequence[float], device=None) -> List[float]:
+    """Sum of each entry over the ranks (edit-distance / length / loss counters of a sharded validation epoch: the ratios are formed
+    AFTER the sum, like torchmetrics' distributed reduction of CharErrorRate's `errors` / `total` states).  One small all-reduce
+    (float64); a no-op without an initialised process group.  `device`: where the collective's buffer lives (the GPU for the nccl =
+    RCCL backend, None = CPU for gloo)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(v) for v in values]
+    use_gpu = device is not None and dist.get_backend() == 'nccl'
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if use_gpu else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu()]

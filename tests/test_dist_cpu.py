@@ -91,7 +91,9 @@ def _grad_worker(rank, world, port, q):
         g = torch.Generator().manual_seed(100 + rank)
         gw, gb = torch.randn((7, 16), generator=g), torch.randn((7,), generator=g)
         reduce_gradients((gw, gb))
-        q.put((rank, gw.numpy(), gb.numpy()))
+        from conformer_ocr_amd.evaluate import reduce_counts
+        counts = reduce_counts([3 + rank, 100 + 10 * rank, 1.5 * (rank + 1)])          # errors, characters, loss sum of each rank's shard
+        q.put((rank, gw.numpy(), gb.numpy(), counts))
     finally:
         dist.destroy_process_group()
 
@@ -117,3 +119,4 @@ def test_world_size_2_gradient_all_reduce():
     np.testing.assert_allclose(res[0][1], (ws[0] + ws[1]).numpy(), rtol=1e-6)
     np.testing.assert_allclose(res[0][2], (bs[0] + bs[1]).numpy(), rtol=1e-6)
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and want_w.shape == (7, 16)
+    assert res[0][3] == res[1][3] == [7.0, 210.0, 4.5]                             # validation counters: summed, identical on both ranks
