@@ -498,7 +498,9 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                 *reinterpret_cast<bf16x2 *>(xa + (c >> 6) * PANEL + row * 128 + ((((c & 63) >> 3) ^ (row & 7)) << 4) + (c & 7) * 2) = o;
             }
         }
+        stamp();
         lds_fence_barrier0();                                // operand image complete; the window (hs) is free
+        stamp();
     }
     // One step: acc[96 rows][32 columns of this wave] += image . ring ; ring <- the 16 fragments at `nxt`.  `side(kk)` is
     // independent VALU work folded into the k-step (the MFMA pipe runs beside it).
