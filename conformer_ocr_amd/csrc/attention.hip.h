@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
     for (int d = 0; d < DT; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    f32x4 negm4 = {0.f, 0.f, 0.f, 0.f};               // -m_run in the accumulator layout (64-key form); zero until the first tile has set it
     float *sk = skew + wave * 48 * SK;
 
     stamp();
@@ -231,25 +232,21 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             // ---- one softmax step per 64-key tile: the two 32-key halves still take the shift tile in turn (it holds 48 band rows),
             // but the cross-lane maximum (two dependent ds_bpermute round trips), the rescale test, the exponentials and the P.V
             // product run once per tile on 16 scores per lane -- the per-wave dependent chain is what bounds this kernel.
+            // Two folds keep the VALU out of the score path (the SIMDs of the CUs that hold three workgroups are issue-bound):
+            //  * the positional products start from C = -m_run (the running reference of this lane's query), so what comes back
+            //    from the shift tile is already "positional score - reference";
+            //  * those shifted values are the C operand of the content products: no add per score either.
             f32x4 sc[4];
             f32x4 keep = {0.f, 0.f, 0.f, 0.f};                    // band tile 2: last of the first half, first of the second
             const int lb0 = 48 - 16 * wave;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int tl = 0; tl < 2; ++tl) {
-                    const int tt = 2 * half + tl;
-                    sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    const unsigned char *kr = ks + (16 * tt + il) * RS;
-#pragma unroll
-                    for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]);
-                }
-#pragma unroll
                 for (int ml = 0; ml < 3; ++ml) {
                     f32x4 rr;
                     if (half == 1 && ml == 0) rr = keep;
                     else {
-                        rr = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        rr = negm4;
                         const unsigned char *pr = ps + (lb0 + 16 * (2 * half + ml) + il) * RS;
 #pragma unroll
                         for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr + frag_off(c))), qv[c], rr);
@@ -262,9 +259,17 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[2 * half + tl][r] += sk[(15 - il + 16 * tl + 4 * g + r) * SK + il];
+                    for (int r = 0; r < 4; ++r) sc[2 * half + tl][r] = sk[(15 - il + 16 * tl + 4 * g + r) * SK + il];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the tile is overwritten
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const int tt = 2 * half + tl;
+                    const unsigned char *kr = ks + (16 * tt + il) * RS;
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]);
+                }
             }
+            // sc = score - m_run (log2 units)
             float tmax = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
             tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(sc[2][0], sc[2][1]), fmaxf(sc[2][2], sc[2][3])), fmaxf(fmaxf(sc[3][0], sc[3][1]), fmaxf(sc[3][2], sc[3][3]))));
             if (j0 + 64 > Tn) {                                      // uniform: only the last tile has keys beyond T (a real branch, see below)
@@ -280,18 +285,23 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            constexpr float LAZY = 8.0f;                             // lazy rescaling: see the 32-key form below
-            if (j0 == 0) {
-                m_run = tmax;
-            } else if (__builtin_amdgcn_ballot_w64(tmax > m_run + LAZY) != 0) {
-                const float m_new = fmaxf(m_run, tmax);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                m_run = m_new;
+            // Lazy rescaling (see the 32-key form below): the reference moves only when some query of the wave exceeds it by > LAZY;
+            // the first tile sets it (key 0 is valid: finite).
+            constexpr float LAZY = 8.0f;
+            if (j0 == 0 || __builtin_amdgcn_ballot_w64(tmax > LAZY) != 0) {
+                const float delta = j0 == 0 ? tmax : fmaxf(tmax, 0.f);
+                const float alpha = j0 == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run = j0 == 0 ? tmax : m_run + delta;
+                negm4 = (f32x4){-m_run, -m_run, -m_run, -m_run};
                 l_run *= alpha;
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[tt][r] -= delta;
             }
             float psum = 0.f;
             frag_t pb[2];
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(sc[tt][r] - m_run);
+                    const float pv = __builtin_amdgcn_exp2f(sc[tt][r]);
                     psum += pv;
                     pb[tt >> 1][4 * (tt & 1) + r] = from_f32<T>(pv);
                 }
