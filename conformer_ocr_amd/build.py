@@ -37,7 +37,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: cannot build libcocr_hip.so')
     os.makedirs(LIB_DIR, exist_ok=True)
+    # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (gfx950 has one unified file).  By default the register allocator parked the
+    # attention / GEMM / frontend accumulators in AGPRs and paid a v_accvgpr_read/write per value the VALU touched (attention: 52 per
+    # key tile; decoder GEMM 7.1 -> 3.5 us, attention 15.8 -> 14.9 us, fused frontend 144 -> 138 us with the flag).
     cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-fgpu-rdc' if False else '-fno-gpu-rdc',
+           '-mllvm', '-amdgpu-mfma-vgpr-form',
            '-Wall', '-Wno-unused-function', '-I', INCLUDE, os.path.join(CSRC, 'cocr_api.hip'), '-o', LIB + '.tmp']
     cmd[1:1] = os.environ.get('COCR_HIPCC_FLAGS', '').split()      # dev builds, e.g. -DCOCR_CHAIN_STAMPS_BUILD
     if verbose:

@@ -30,6 +30,14 @@ __device__ __forceinline__ int xcd_remap_i(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// max of three without the NaN-quieting v_max x, x the compiler puts in front of every fmaxf operand (scores are never NaN: finite
+// products, or -inf from the tail mask)
+__device__ __forceinline__ float max3_f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 #define COCR_POS_CENTER 4999
 #define COCR_POS_ROWS 9999
 
@@ -218,6 +226,10 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     for (int d = 0; d < DT; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 negm4 = {0.f, 0.f, 0.f, 0.f};               // -m_run in the accumulator layout (64-key form); zero until the first tile has set it
+    f32x4 osum = {0.f, 0.f, 0.f, 0.f};                // 64-key form: row 0 (register 0 of lanes 0..15) = softmax denominator of query `lane`
+    frag_t ones;                                      // A operand whose row 0 is all ones
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = il == 0 ? (T)1.0f : (T)0.0f;
     float *sk = skew + wave * 48 * SK;
 
     stamp();
@@ -270,8 +282,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                 }
             }
             // sc = score - m_run (log2 units)
-            float tmax = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-            tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(sc[2][0], sc[2][1]), fmaxf(sc[2][2], sc[2][3])), fmaxf(fmaxf(sc[3][0], sc[3][1]), fmaxf(sc[3][2], sc[3][3]))));
+            float tmax = max3_f(sc[0][0], sc[0][1], sc[0][2]);
+            tmax = max3_f(tmax, sc[0][3], sc[1][0]);
+            tmax = max3_f(tmax, sc[1][1], sc[1][2]);
+            tmax = max3_f(tmax, sc[1][3], sc[2][0]);
+            tmax = max3_f(tmax, sc[2][1], sc[2][2]);
+            tmax = max3_f(tmax, sc[2][3], sc[3][0]);
+            tmax = max3_f(tmax, sc[3][1], sc[3][2]);
+            tmax = max3_f(tmax, sc[3][3], sc[3][3]);
             if (j0 + 64 > Tn) {                                      // uniform: only the last tile has keys beyond T (a real branch, see below)
                 asm volatile("; keys beyond the line" ::: "memory");
                 tmax = -INFINITY;
@@ -283,8 +301,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                         tmax = fmaxf(tmax, sc[tt][r]);
                     }
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            { const float x = __shfl_xor(tmax, 16, 64); tmax = max3_f(tmax, x, x); }
+            { const float x = __shfl_xor(tmax, 32, 64); tmax = max3_f(tmax, x, x); }
             // Lazy rescaling (see the 32-key form below): the reference moves only when some query of the wave exceeds it by > LAZY;
             // the first tile sets it (key 0 is valid: finite).
             constexpr float LAZY = 8.0f;
@@ -293,7 +311,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                 const float alpha = j0 == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
                 m_run = j0 == 0 ? tmax : m_run + delta;
                 negm4 = (f32x4){-m_run, -m_run, -m_run, -m_run};
-                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) osum[r] *= alpha;
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -303,17 +322,15 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sc[tt][r] -= delta;
             }
-            float psum = 0.f;
             frag_t pb[2];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(sc[tt][r]);
-                    psum += pv;
-                    pb[tt >> 1][4 * (tt & 1) + r] = from_f32<T>(pv);
-                }
-            l_run += psum;
+                for (int r = 0; r < 4; ++r) pb[tt >> 1][4 * (tt & 1) + r] = from_f32<T>(__builtin_amdgcn_exp2f(sc[tt][r]));
+            // the softmax denominators on the matrix cores as well: one more row tile whose row 0 is all ones (2 MFMAs per key tile
+            // instead of 16 VALU adds; the sum is over the SAME bf16-rounded probabilities the numerator uses)
+            osum = mma16(ones, pb[0], osum);
+            osum = mma16(ones, pb[1], osum);
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 o[d] = mma16(load_vt_frag<SWZ>(vs, RS, 0, d, il, g, T()), pb[0], o[d]);
@@ -412,8 +429,12 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     if (stamps && tid == 0) stamps[64 + 3 * logical + 1] = wall_clock64();
 #endif
     // ---- normalise and store: lane holds head dims 16 d + 4g + r of query i0 + il
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    if constexpr (MERGE) {
+        l_run = __shfl(osum[0], il, 64);              // the denominator of query il sits in lane il
+    } else {
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_run;
     if (i0 + il < Tn) {
         T *dst = ctx + ((size_t)b * Tn + i0 + il) * (heads * dh) + hh * dh;

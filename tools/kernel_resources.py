@@ -5,7 +5,7 @@ import subprocess
 import sys
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-I', ROOT + '/include',
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-mllvm', '-amdgpu-mfma-vgpr-form', '-I', ROOT + '/include',
        ROOT + '/conformer_ocr_amd/csrc/cocr_api.hip', '-o', '/tmp/_res.so', '-Rpass-analysis=kernel-resource-usage']
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, []
