@@ -504,7 +504,10 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     }
     // One step: acc[96 rows][32 columns of this wave] += image . ring ; ring <- the 16 fragments at `nxt`.  `side(kk)` is
     // independent VALU work folded into the k-step (the MFMA pipe runs beside it).
-    auto step = [&](const unsigned char *img, f32x4 (&acc)[MT][2], const T *nxt, auto &&side) {
+    // `fresh`: the accumulators start from zero -- the first k-step's MFMAs take the constant 0 as their C operand instead of 48
+    // registers zeroed by 48 v_mov (the VALU is the scarce unit of this kernel).
+    auto step = [&](const unsigned char *img, f32x4 (&acc)[MT][2], const T *nxt, auto &&side, auto FRESH) {
+        constexpr bool fresh = decltype(FRESH)::value;
 #pragma unroll
         for (int kk = 0; kk < KC1; ++kk) {
             // row tiles in two halves: 12 operand registers live instead of 24 (the 96-row FFN stage is at the 256-register limit)
@@ -517,7 +520,8 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < HT; ++i) acc[h0 + i][j] = mma16(ring[2 * kk + j], a[i], acc[h0 + i][j]);
+                    for (int i = 0; i < HT; ++i)
+                        acc[h0 + i][j] = mma16(ring[2 * kk + j], a[i], (fresh && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[h0 + i][j]);
             }
             fill(nxt, 2 * kk);
             fill(nxt, 2 * kk + 1);
@@ -677,8 +681,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             const Bias2 bb = load_bias(st.bias);
             const Resid res = load_resid(st);
             f32x4 acc[MT][2];
-            zero(acc);
-            step(xa, acc, after, no_side);
+            step(xa, acc, after, no_side, std::true_type{});
             stamp();
             lds_fence_barrier();                             // hs (hidden chunks / output tiles of the previous stage) is free
             stage_rows(acc, bb, st.alpha);
@@ -707,8 +710,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             request_ln_params(st);
             zero(acc2);
             bb = load_bias(st.bias);
-            zero(acc1);
-            step(xa, acc1, nchunks > 1 ? w1(1) : w2(0), no_side);                      // P1(0)
+            step(xa, acc1, nchunks > 1 ? w1(1) : w2(0), no_side, std::true_type{});    // P1(0)
             stamp();
 #pragma unroll
             for (int t2 = 0; t2 < 2 * MT; ++t2) silu_tile(t2, hs);                        // S(0)
@@ -717,22 +719,21 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             stamp();
             for (int c = 1; c < nchunks; ++c) {
                 bb = load_bias(st.bias + c * 256);
-                zero(acc1);
-                step(xa, acc1, w2(c - 1), no_side);                                       // P1(c)
+                step(xa, acc1, w2(c - 1), no_side, std::true_type{});                     // P1(c)
                 stamp();
                 unsigned char *hb = hs + (c & 1) * IMG;
                 step(hs + ((c - 1) & 1) * IMG, acc2, c + 1 < nchunks ? w1(c + 1) : w2(c),    // P2(c-1) beside S(c)
                      [&](auto, int kk) {                                                  // the 2 MT tiles spread over the 8 k-steps
 #pragma unroll
                          for (int t2 = 0; t2 < 2 * MT; ++t2) if ((t2 * 8) / (2 * MT) == kk) silu_tile(t2, hb);
-                     });
+                     }, std::false_type{});
                 stamp();
                 lds_fence_barrier();
                 stamp();
             }
             const Bias2 b2 = load_bias(st.bias2);
             const Resid res = load_resid(st);                // (the hidden-chunk accumulators are dead: their registers carry the rows)
-            step(hs + ((nchunks - 1) & 1) * IMG, acc2, after, no_side);                  // P2(last)
+            step(hs + ((nchunks - 1) & 1) * IMG, acc2, after, no_side, std::false_type{});   // P2(last)
             stamp();
             lds_fence_barrier();                             // every wave is done reading the hidden chunks
             stage_rows(acc2, b2, st.alpha);
@@ -747,8 +748,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const Bias2 bb = load_bias(st.bias + s2 * 256);          // v[0]: value bias, v[1]: gate bias
                 f32x4 acc[MT][2];
-                zero(acc);
-                step(xa, acc, s2 == 0 ? st.W + (size_t)(8 + wave) * SLICE : after, no_side);
+                step(xa, acc, s2 == 0 ? st.W + (size_t)(8 + wave) * SLICE : after, no_side, std::true_type{});
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int row = 16 * i + r16;
@@ -766,8 +766,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
             for (int s3 = 0; s3 < 3; ++s3) {
                 const Bias2 bb = load_bias(st.bias + s3 * 256);
                 f32x4 acc[MT][2];
-                zero(acc);
-                step(xa, acc, s3 < 2 ? st.W + (size_t)((s3 + 1) * 8 + wave) * SLICE : after, no_side);
+                step(xa, acc, s3 < 2 ? st.W + (size_t)((s3 + 1) * 8 + wave) * SLICE : after, no_side, std::true_type{});
                 stamp();
                 unsigned char *tile = hs + (s3 & 1) * (BMC * OS);
 #pragma unroll
