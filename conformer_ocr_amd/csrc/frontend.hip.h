@@ -36,6 +36,19 @@ __global__ __launch_bounds__(256) void frontend_pack_kernel(const float *__restr
     }
 }
 
+// ReLU of four bf16 values as two packed signed-16-bit maxima with 0: a bf16 is negative iff its bit pattern is a negative int16, and
+// rounding commutes with ReLU (round-to-nearest keeps the sign), so this equals rounding max(x, 0).  fmaxf / fmed3 on the fp32 values
+// cost 8 VALU operations per 4 values here (the compiler quiets a possible signalling NaN in front of each maximum).
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_pack2(float a, float b) {        // bf16(max(a, 0)) | bf16(max(b, 0)) << 16
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2 h = __builtin_convertvector((f32x2_t){a, b}, bf16x2);   // one v_cvt_pk_bf16_f32
+    const s16x2_t zero = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, h), zero));
+}
+__device__ __forceinline__ u32x2_t relu_bf16x4(const f32x4 &v) { return (u32x2_t){relu_pack2(v[0], v[1]), relu_pack2(v[2], v[3])}; }
+
 template <typename TIn>
 __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__ X, int H, int W, int T1, int F1, int Tn,
                                                          const bf16_t *__restrict__ w0f, const float *__restrict__ b0,
@@ -128,6 +141,7 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
         valid[u] = t1 >= 0 && t1 < T1 && f1 < F1;
         zoff[u] = (wave + 8 * u < ntile && f1 + 1 < ZR) ? (a * ZR + f1 + 1) * ZC : NA * ZR * ZC;      // else: the dump row behind the tile
     }
+    const bool all_valid = __builtin_amdgcn_ballot_w64(valid[0] && valid[1] && valid[2] && valid[3]) == ~0ull;
     // depthwise fragments of (pass, blk): one pass ahead in registers
     bf16x8 dwn[5];
     auto request_dw = [&](int pass) {
@@ -156,18 +170,20 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) c0[u][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wf[nt], pf[u], bias0[nt], 0, 0, 0);
+        // (interior workgroups -- all pixels of all four tiles inside Z1 -- skip the per-value zero select: one uniform branch per
+        // pass around two straight-line copies of the epilogue)
+        auto z1_epilogue = [&](auto MASKED) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 a = c0[u][nt];
-                const bf16x4 o = {(T)__builtin_amdgcn_fmed3f(a[0], 0.0f, INFINITY), (T)__builtin_amdgcn_fmed3f(a[1], 0.0f, INFINITY),
-                                  (T)__builtin_amdgcn_fmed3f(a[2], 0.0f, INFINITY), (T)__builtin_amdgcn_fmed3f(a[3], 0.0f, INFINITY)};      // ReLU
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 ob = __builtin_bit_cast(u32x2, o);
-                if (!valid[u]) ob = (u32x2){0u, 0u};                  // outside Z1: the depthwise conv's zero padding
-                *reinterpret_cast<u32x2 *>(z1 + zoff[u] + 16 * nt + 4 * g) = ob;       // (tiles beyond the last: a dump row)
-            }
+                for (int nt = 0; nt < 4; ++nt) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 ob = relu_bf16x4(c0[u][nt]);
+                    if (decltype(MASKED)::value && !valid[u]) ob = (u32x2){0u, 0u};      // outside Z1: the depthwise conv's zero padding
+                    *reinterpret_cast<u32x2 *>(z1 + zoff[u] + 16 * nt + 4 * g) = ob;       // (tiles beyond the last: a dump row)
+                }
+        };
+        if (all_valid) z1_epilogue(std::false_type{}); else z1_epilogue(std::true_type{});
         stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -214,8 +230,8 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = 16 * i + r16;
-            const bf16x4 o = {(T)fmaxf(acc[i][j][0], 0.f), (T)fmaxf(acc[i][j][1], 0.f), (T)fmaxf(acc[i][j][2], 0.f), (T)fmaxf(acc[i][j][3], 0.f)};
-            *reinterpret_cast<bf16x4 *>(tile + row * OS + (32 * wave + 16 * j + 4 * g) * 2) = o;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2 *>(tile + row * OS + (32 * wave + 16 * j + 4 * g) * 2) = relu_bf16x4(acc[i][j]);
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
