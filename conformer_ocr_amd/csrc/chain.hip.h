@@ -589,7 +589,7 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
         const int m = min(m0 + (BMC / 8) * wave + 4 * pass + rl, mend - 1);
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-            out[v] = st.has_resid ? *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            out[v] = *reinterpret_cast<const f32x4 *>(p.x + (size_t)m * D + 4 * (cl + 16 * v));      // (every stage of these chains has a residual: no branch in front of the product step)
     };
     auto load_resid = [&](const ChainStage &st) {
         Resid r;
