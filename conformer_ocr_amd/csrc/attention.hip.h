@@ -436,7 +436,18 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
         l_run += __shfl_xor(l_run, 32, 64);
     }
     const float inv = 1.0f / l_run;
-    if (i0 + il < Tn) {
+    if (dh == DHP) {
+        // common case (no padded head dims): straight-line 8-/16-byte stores, rows beyond T go to nowhere by predication only
+        if (i0 + il < Tn) {
+            T *dst = ctx + ((size_t)b * Tn + i0 + il) * (heads * DHP) + hh * DHP + 4 * g;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const f32x4 r4 = o[d] * inv;
+                if constexpr (sizeof(T) == 2) { bf16x4 w = {(T)r4[0], (T)r4[1], (T)r4[2], (T)r4[3]}; *reinterpret_cast<bf16x4 *>(dst + 16 * d) = w; }
+                else { *reinterpret_cast<f32x4 *>(dst + 16 * d) = r4; }
+            }
+        }
+    } else if (i0 + il < Tn) {
         T *dst = ctx + ((size_t)b * Tn + i0 + il) * (heads * dh) + hh * dh;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
