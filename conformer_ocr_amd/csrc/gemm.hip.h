@@ -436,7 +436,6 @@ template <typename T, int BM, int BN, int NST, typename Epi>
 __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) {
     constexpr int ROWB = 128;
     constexpr int BK = ROWB / sizeof(T);
-    constexpr int EPC = 16 / sizeof(T);
     constexpr int MI = BM / 32, NI = BN / 32;
     constexpr int PER = BM / 32 + BN / 32;                 // DMA wave-instructions per wave per k-tile
     constexpr int STAGE = (BM + BN) * ROWB;
@@ -453,21 +452,33 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) 
     const int nk = K / BK;
     if (p.k_zstride) { p.A += (size_t)blockIdx.y * p.k_zstride; p.W += (size_t)blockIdx.y * p.k_zstride; }
 
-    auto issue = [&](int kt) {
-        unsigned char *st = smem + (kt % NST) * STAGE;
-        const int k0 = kt * BK, lrow = lane >> 3, cpos = lane & 7;
+    // Per-lane byte offsets of this thread's DMA pieces are loop-invariant (row clamp + swizzled chunk); a k-tile only moves the
+    // UNIFORM base by 128 bytes, so an issue costs no vector arithmetic (it was ~60 VALU instructions per k-tile beside 32 MFMAs).
+    // 32-bit offsets: the launchers check (rows - 1) * ld * sizeof(T) + 128 < 4 GiB.
+    unsigned offA[BM / 32], offW[BN / 32];
+    {
+        const int lrow = lane >> 3, cpos = lane & 7;
 #pragma unroll
         for (int i = 0; i < BM / 32; ++i) {
-            const int rg = wave + 4 * i, row = rg * 8 + lrow;
-            const T *src = p.A + (size_t)min(m0 + row, M - 1) * p.lda + k0 + ((cpos ^ (row & 7)) * EPC);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + rg * 1024), 16, 0, 0);
+            const int row = (wave + 4 * i) * 8 + lrow;
+            offA[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)(p.lda * (int)sizeof(T)) + ((cpos ^ (row & 7)) << 4);
         }
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) {
-            const int rg = wave + 4 * i, row = rg * 8 + lrow;
-            const T *src = p.W + (size_t)min(n0 + row, N - 1) * p.ldw + k0 + ((cpos ^ (row & 7)) * EPC);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + BM * ROWB + rg * 1024), 16, 0, 0);
+            const int row = (wave + 4 * i) * 8 + lrow;
+            offW[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)(p.ldw * (int)sizeof(T)) + ((cpos ^ (row & 7)) << 4);
         }
+    }
+    auto issue = [&](int kt) {
+        unsigned char *st = smem + (kt % NST) * STAGE;
+        const char *abase = reinterpret_cast<const char *>(p.A) + (size_t)kt * ROWB;      // uniform
+        const char *wbase = reinterpret_cast<const char *>(p.W) + (size_t)kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + offA[i]), (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wbase + offW[i]), (lds_ptr_t)(st + BM * ROWB + (wave + 4 * i) * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
@@ -628,7 +639,9 @@ static inline hipError_t launch_gemm(hipStream_t s, const T *A, int lda, const T
     GemmArgs<T> a{A, lda, W, ldw, M, N, K, 0};
     constexpr int BK = 128 / (int)sizeof(T);
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    if (K % BK == 0) {
+    // the ring kernel addresses its operand rows with 32-bit byte offsets from a uniform base
+    const bool off32 = (size_t)M * lda * sizeof(T) < ((size_t)1 << 32) - 256 && (size_t)N * ldw * sizeof(T) < ((size_t)1 << 32) - 256;
+    if (K % BK == 0 && off32) {
         if (t128 >= 1024) return launch_ring_cfg<T, 128, 128, 2, Epi>(s, a, epi);
         if (N >= 512) return launch_ring_cfg<T, 64, 128, 3, Epi>(s, a, epi);
         return launch_ring_cfg<T, 64, 64, 3, Epi>(s, a, epi);
@@ -753,6 +766,7 @@ static inline hipError_t launch_gemm_splitk(hipStream_t s, const T *A, int lda, 
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int BM = COCR_FO_BM, BN = COCR_FO_BN, NST = COCR_FO_NST;
     if (K % (splits * BK)) return hipErrorInvalidValue;
+    if ((size_t)M * lda * sizeof(T) >= ((size_t)1 << 32) - 256 || (size_t)N * ldw * sizeof(T) >= ((size_t)1 << 32) - 256) return hipErrorInvalidValue;
     GemmArgs<T> a{A, lda, W, ldw, M, N, K / splits, K / splits};
     EpiStoreF32 e{partial, N, nullptr, N};
     e.zstride = (size_t)M * N;
