@@ -46,7 +46,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
     cmd[1:1] = os.environ.get('COCR_HIPCC_FLAGS', '').split()      # dev builds, e.g. -DCOCR_CHAIN_STAMPS_BUILD
     if verbose:
         print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+    except subprocess.CalledProcessError:
+        # a compiler without that backend option: same code, accumulators where the register allocator puts them
+        if '-amdgpu-mfma-vgpr-form' not in cmd:
+            raise
+        i = cmd.index('-amdgpu-mfma-vgpr-form')
+        del cmd[i - 1:i + 1]
+        if verbose:
+            print('retrying without -amdgpu-mfma-vgpr-form', flush=True)
+        subprocess.check_call(cmd)
     os.replace(LIB + '.tmp', LIB)
     return LIB
 
