@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.hip_util import hip_tap, oracle_taps, run_hip
+from tests.hip_util import hip_tap, make_engine, oracle_taps, run_hip
 
 pytestmark = pytest.mark.gpu
 
@@ -169,7 +169,7 @@ def test_small_batch_form_of_the_chain_kernels(case):
     np.testing.assert_array_equal(small, full[:4])
 
 
-@pytest.mark.parametrize('n,w', [(1, 17), (2, 33), (3, 100), (5, 513), (7, 1023), (2, 2048), (160, 120)])
+@pytest.mark.parametrize('n,w', [(1, 17), (2, 33), (3, 100), (5, 513), (3, 780), (7, 1023), (2, 2048), (1, 8000), (160, 120)])
 def test_cfg2_kernels_on_odd_shapes(n, w):
     """The measured configuration's kernels (fused frontend, 96- / 32-row chains, rel-pos attention) on awkward batch shapes:
     one frame groups that are not multiples of 4, a single line, very short and very long lines, more rows than one launch
@@ -185,3 +185,20 @@ def test_cfg2_kernels_on_odd_shapes(n, w):
     dev = float(np.abs(logits - ref).max())
     _log(f'cfg2_1block_n{n}_w{w}', {'max_abs_logit_dev': dev, 'logit_range': float(np.abs(ref).max())})
     assert dev <= 0.25, dev
+
+
+def test_longest_supported_line_and_the_error_beyond_it():
+    """4900 output frames is the documented limit (the positional table has 9999 rows): one frame more is refused with
+    NotImplementedError (COCR_EUNSUPPORTED), not computed wrongly."""
+    from conformer_ocr_amd import synth
+    hp = synth.hparams('cfg2', num_encoder_layers=1)
+    state = synth.make_state_dict(hp, seed=5, decoder_gain=8.0)
+    eng = make_engine(hp, state, 'bf16')
+    w_ok = 4 * 4900 - 3                         # T = 4900
+    assert eng.out_len(w_ok) == 4900 and eng.out_len(w_ok + 4) == 4901
+    x = torch.zeros((1, hp.height, w_ok + 4), dtype=torch.uint8, device='cuda')
+    with pytest.raises(NotImplementedError):
+        eng.forward(x, [w_ok + 4])
+    logits, out_lens = eng.forward(x[:, :, :w_ok].contiguous(), [w_ok])
+    torch.cuda.synchronize()
+    assert logits.shape == (1, 4900, hp.num_classes) and out_lens.tolist() == [4900] and bool(torch.isfinite(logits).all())
