@@ -702,10 +702,21 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                 const int i = tIdx >> 1, j = tIdx & 1;
                 const int jj = 32 * wave + 16 * j + 4 * g;               // hidden column inside the chunk
                 const int ch16 = (jj & 63) >> 3, row = 16 * i + r16;
-                bf16x4 hv;
+                // packed fp32 arithmetic around the two transcendentals (a SIMD issues VALU and MFMA instructions one at a time, so
+                // this epilogue is paid in full beside the product step: 5 packed + 4 transcendental + 1 convert per value pair)
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                const f32x4 v4 = acc1[i][j] + bb.v[j];
+                unsigned packed[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hv[q] = (T)silu_f(acc1[i][j][q] + bb.v[j][q]);
-                *reinterpret_cast<bf16x4 *>(hb + (jj >> 6) * PANEL + row * 128 + ((ch16 ^ (row & 7)) << 4) + ((jj & 7) >> 2) * 8) = hv;
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2_t v = {v4[2 * h], v4[2 * h + 1]};
+                    f32x2_t e = v * (f32x2_t){-1.44269504088896340736f, -1.44269504088896340736f};
+                    e = (f32x2_t){__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + (f32x2_t){1.0f, 1.0f};
+                    const f32x2_t o = v * (f32x2_t){__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                    packed[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
+                }
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2_t *>(hb + (jj >> 6) * PANEL + row * 128 + ((ch16 ^ (row & 7)) << 4) + ((jj & 7) >> 2) * 8) = (u32x2_t){packed[0], packed[1]};
             };
             request_ln_params(st);
             zero(acc2);
