@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Random batch shapes through the measured configuration's kernels (cfg2, one encoder block, bf16) against the fp32 CPU oracle:
+a one-off robustness sweep beyond tests/test_hip_parity.py::test_cfg2_kernels_on_odd_shapes.
+
+    python tools/fuzz_shapes.py [--cases 40] [--seed 0]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conformer_ocr_amd import synth  # noqa: E402
+from tests.hip_util import oracle_taps, run_hip  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=40)
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+    g = np.random.default_rng(args.seed)
+    hp = synth.hparams('cfg2', num_encoder_layers=1)
+    state = synth.make_state_dict(hp, seed=99, decoder_gain=8.0)
+    worst = 0.0
+    for k in range(args.cases):
+        n = int(g.integers(1, 7)) if k % 5 else int(g.integers(30, 70))
+        w = int(g.integers(9, 1600)) if k % 5 else int(g.integers(9, 400))
+        widths = sorted((int(x) for x in g.integers(9, w + 1, size=n)), reverse=True)
+        widths[0] = w
+        image, lens = synth.make_lines(n, hp.height, w, seed=1000 + k, widths=widths)
+        _, logits, out_lens = run_hip(hp, state, image, lens, 'bf16', as_u8=bool(k % 2))
+        ref, ref_lens, _ = oracle_taps(hp, state, np.rint(image * 255).astype(np.float32) / 255 if k % 2 else image, lens)
+        assert out_lens.tolist() == ref_lens.tolist(), (n, w, out_lens, ref_lens)
+        dev = float(np.abs(logits - ref).max())
+        worst = max(worst, dev)
+        flag = '' if dev <= 0.25 and np.isfinite(logits).all() else '   <-- OUT OF BAND'
+        print(f'case {k:3d}: n={n:3d} w={w:5d} T={logits.shape[1]:4d} max|dlogit|={dev:.4f}{flag}', flush=True)
+    print('worst', worst)
+    return 0 if worst <= 0.25 else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())
