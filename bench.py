@@ -72,6 +72,13 @@ def kernel_table(hp, n, w, dtype):
     }
 
 
+def cus_occupied(family, rows):
+    """CUs a launch of `family` can occupy (MI355X: 256): the 96-row chain kernels run one workgroup per CU."""
+    if family.startswith('chain_') and rows >= 4800:
+        return min(256, -(-rows // 96))
+    return 256
+
+
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (collected offline with
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` on this bench command; tools/summarize_rocprof.py), or None."""
@@ -260,7 +267,10 @@ def main():
         d = kernels[dom]
         roof = {'kernel': dom, 'bound': 'hbm' if d['bound'] == 'hbm' else 'mfma', 'achieved': d['achieved'], 'peak': d['peak'],
                 'unit': d['unit'], 'frac': d['frac'], 'traffic': pmc_traffic(dom), 'avg_ms': d['avg_ms'], 'share_of_step': d['share'],
-                'algorithmic_per_launch': table[dom][1], 'event_pair_overhead_ms': round(ovh, 5), 'traffic_source': 'profiles/*_pmc_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                'algorithmic_per_launch': table[dom][1], 'event_pair_overhead_ms': round(ovh, 5),
+                # the 96-row chain kernels launch ceil(rows / 96) workgroups of one per CU: `frac` prices them against the WHOLE chip
+                'cus_occupied': cus_occupied(dom, args.batch * T_out), 'frac_of_occupied_cus': round(d['frac'] * 256.0 / cus_occupied(dom, args.batch * T_out), 5),
+                'traffic_source': 'profiles/*_pmc_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                 'separate passes, 2*FETCH+WRITE bytes per launch)'}
 
     cpu = None
