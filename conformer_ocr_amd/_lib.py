@@ -5,6 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import warnings
 from typing import Optional
 
 from . import build as _build
@@ -75,9 +76,16 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         if build_if_missing and not _build.up_to_date():
             try:
                 _build.build(verbose=False)
-            except Exception as e:  # a prebuilt library that travelled with the tree is still usable
+            except Exception as e:
                 if not os.path.exists(path):
                     raise RuntimeError(f'libcocr_hip.so is missing and cannot be built: {e}') from e
+                # a library built from OTHER sources than the tree's: numbers and test results would describe kernels that are
+                # not the committed ones.  Refused unless explicitly allowed.
+                msg = (f'libcocr_hip.so was built from sources {_build.built_hash() or "?"} but the tree is {_build.source_hash()} '
+                       f'and the rebuild failed ({e})')
+                if os.environ.get('COCR_ALLOW_STALE_LIB') != '1':
+                    raise RuntimeError(msg + '; set COCR_ALLOW_STALE_LIB=1 to load the stale library anyway') from e
+                warnings.warn(msg + '; loading the STALE library (COCR_ALLOW_STALE_LIB=1)')
         if not os.path.exists(path):
             raise RuntimeError(f'{path} not found: run `python -m conformer_ocr_amd.build` (no CPU fallback exists)')
         lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
@@ -85,6 +93,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)      # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
+        ver = (lib.cocr_version() or b'').decode()
+        if _build.built_hash() and f'src={_build.built_hash()}' not in ver and os.environ.get('COCR_ALLOW_STALE_LIB') != '1':
+            raise RuntimeError(f'{path} reports "{ver}" but its build record says src={_build.built_hash()}: rebuild with '
+                               '`python -m conformer_ocr_amd.build --force`')
         _lib = lib
         return lib
 

@@ -23,11 +23,30 @@ def sources():
     return srcs + [os.path.join(INCLUDE, 'cocr.h')]
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and the C header (names + contents): compiled into the library (`cocr_version()`) and
+    written beside it, so that a library built from other sources is recognised whatever the file times say (the .so is
+    git-ignored and travels with the tree to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sources():
+        h.update(os.path.basename(s).encode() + b'\0')
+        with open(s, 'rb') as fp:
+            h.update(fp.read())
+    h.update(os.environ.get('COCR_HIPCC_FLAGS', '').encode())
+    return h.hexdigest()[:16]
+
+
+def built_hash() -> str:
+    try:
+        with open(LIB + '.srchash') as fp:
+            return fp.read().strip()
+    except OSError:
+        return ''
+
+
 def up_to_date() -> bool:
-    if not os.path.exists(LIB):
-        return False
-    t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(s) <= t for s in sources())
+    return os.path.exists(LIB) and built_hash() == source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -42,7 +61,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # key tile; decoder GEMM 7.1 -> 3.5 us, attention 15.8 -> 14.9 us, fused frontend 144 -> 138 us with the flag).
     cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-fgpu-rdc' if False else '-fno-gpu-rdc',
            '-mllvm', '-amdgpu-mfma-vgpr-form',
-           '-Wall', '-Wno-unused-function', '-I', INCLUDE, os.path.join(CSRC, 'cocr_api.hip'), '-o', LIB + '.tmp']
+           '-Wall', '-Wno-unused-function', f'-DCOCR_SRC_HASH="{source_hash()}"', '-I', INCLUDE, os.path.join(CSRC, 'cocr_api.hip'), '-o', LIB + '.tmp']
+    src_hash = source_hash()
     cmd[1:1] = os.environ.get('COCR_HIPCC_FLAGS', '').split()      # dev builds, e.g. -DCOCR_CHAIN_STAMPS_BUILD
     if verbose:
         print(' '.join(cmd), flush=True)
@@ -58,6 +78,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print('retrying without -amdgpu-mfma-vgpr-form', flush=True)
         subprocess.check_call(cmd)
     os.replace(LIB + '.tmp', LIB)
+    with open(LIB + '.srchash.tmp', 'w') as fp:
+        fp.write(src_hash + '\n')
+    os.replace(LIB + '.srchash.tmp', LIB + '.srchash')
     return LIB
 
 

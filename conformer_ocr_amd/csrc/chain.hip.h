@@ -39,6 +39,8 @@ struct ChainStage {
     int store_x, store_xn;             // write the fp32 stream / the normalised operand back to global after this stage
     bf16_t *out;           // GLU: (M, 256)
     bf16_t *q, *k, *v;     // QKV
+    float *tap_pre, *tap_post;         // debug taps (TAPS instantiation of chain96_kernel only): (M, 256) fp32 copies of the stream after this
+                                       // stage's residual add, and (chained LayerNorms) after the first LayerNorm; null = not wanted
 };
 
 struct ChainArgs {
@@ -48,6 +50,7 @@ struct ChainArgs {
     int M, nstages;
     const bf16_t *dw_in;   // 96-row form with the depthwise-conv prologue: GLU output (M, 256); A0 unused
     const float *dw_w, *dw_b;      // BatchNorm-folded depthwise taps [k][256] and bias [256]
+    bf16_t *tap_dw;        // debug tap (TAPS instantiation): (M, 256) copy of the depthwise-conv prologue's output, or null
     float *dump;           // >= 16 KiB scratch: branch-free sink for the stores of rows beyond M (16 bytes per thread + slack)
     unsigned long long *stamps;   // dev: cycle stamps of workgroup 0 / wave 0 (COCR_CHAIN_STAMPS), else null
     int dh, dhp, heads, T_, Tp;       // attention layout of the QKV stage
@@ -365,7 +368,9 @@ __device__ __forceinline__ float row16_sum(float v) {      // (every lane is wri
 // written straight into the operand image -- one launch and one (M, 256) round trip less per block.
 // MT = 16-row tiles per workgroup: 6 (96 rows: the throughput form) or 2 (32 rows: three times the workgroups for small
 // batches, where the latency of one workgroup's serial chain is the forward's latency).
-template <int MT, int DWK, int K0, int K1, int K2, int K3>
+// TAPS: the debug instantiation (cocr_set_debug): the SAME code plus copies of the values that otherwise never leave the chip or are
+// overwritten inside the launch (stream after each residual add / first LayerNorm, depthwise output) into the stages' tap buffers.
+template <int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS = false>
 __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     typedef bf16_t T;
     static_assert(MT == 6 || MT == 2, "rows per wave in the LayerNorm epilogue must be a multiple of 4");
@@ -496,6 +501,9 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                 const int row = r0 + i;
                 const bf16x2 o = {(T)silu_f(acc[i][0]), (T)silu_f(acc[i][1])};
                 *reinterpret_cast<bf16x2 *>(xa + (c >> 6) * PANEL + row * 128 + ((((c & 63) >> 3) ^ (row & 7)) << 4) + (c & 7) * 2) = o;
+                if constexpr (TAPS) {
+                    if (p.tap_dw && m0 + row < mend) *reinterpret_cast<bf16x2 *>(p.tap_dw + (size_t)(m0 + row) * D + c) = o;
+                }
             }
         }
         stamp();
@@ -642,6 +650,11 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                     t[v] = *reinterpret_cast<const f32x4 *>(hs + row * RS + 16 * (cl + 16 * v)) + xr[pass][v];      // (zeros without a residual)
                 float *xrow = live ? p.x + (size_t)(m0 + row) * D + 4 * cl : p.dump + 4 * tid;
                 const int xstep = live ? 64 : 0;
+                if constexpr (TAPS) {
+                    if (live && st.tap_pre)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(st.tap_pre + (size_t)(m0 + row) * D + 4 * cl + 64 * v) = t[v];
+                }
                 if constexpr (!chained_c) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + xstep * v) = t[v];
@@ -650,6 +663,11 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
                     normalise(t, 0);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(xrow + xstep * v) = t[v];
+                    if constexpr (TAPS) {
+                        if (live && st.tap_post)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4 *>(st.tap_post + (size_t)(m0 + row) * D + 4 * cl + 64 * v) = t[v];
+                    }
                     normalise(t, 1);
                 }
                 const bool wxn = live && st.store_xn;
@@ -813,10 +831,10 @@ __global__ __launch_bounds__(512) void chain96_kernel(ChainArgs p) {
     run_stage(std::integral_constant<int, K3>{}, p.st[3], first_slice(0));
 }
 
-template <int MT, int DWK, int K0, int K1, int K2, int K3>
+template <int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS>
 static inline hipError_t launch_chain96_mt(hipStream_t s, const ChainArgs &a) {
     const size_t lds = (size_t)3 * 4 * (16 * MT) * 128 + 4096 + 4096 + 2048;      // operand image, 2 hidden images (+ slack), LayerNorm parameters, row offsets + frame indices
-    auto kern = chain96_kernel<MT, DWK, K0, K1, K2, K3>;
+    auto kern = chain96_kernel<MT, DWK, K0, K1, K2, K3, TAPS>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, 16 * MT)), dim3(512), lds, s, a);
@@ -824,21 +842,22 @@ static inline hipError_t launch_chain96_mt(hipStream_t s, const ChainArgs &a) {
 }
 // 96-row workgroups when they fill a useful share of the chip (M >= 4800 rows: 50 workgroups), 32-row workgroups below
 template <int DWK, int K0, int K1, int K2, int K3>
-static inline hipError_t launch_chain96_cfg(hipStream_t s, const ChainArgs &a) {
-    return a.M >= COCR_CHAIN_SMALL_M ? launch_chain96_mt<6, DWK, K0, K1, K2, K3>(s, a) : launch_chain96_mt<2, DWK, K0, K1, K2, K3>(s, a);
+static inline hipError_t launch_chain96_cfg(hipStream_t s, const ChainArgs &a, bool taps) {
+    if (taps) return a.M >= COCR_CHAIN_SMALL_M ? launch_chain96_mt<6, DWK, K0, K1, K2, K3, true>(s, a) : launch_chain96_mt<2, DWK, K0, K1, K2, K3, true>(s, a);
+    return a.M >= COCR_CHAIN_SMALL_M ? launch_chain96_mt<6, DWK, K0, K1, K2, K3, false>(s, a) : launch_chain96_mt<2, DWK, K0, K1, K2, K3, false>(s, a);
 }
 
 // the chain shapes the forward uses; stage weights point at the fragment-major copies
-static inline hipError_t launch_chain96(hipStream_t s, const ChainArgs &a) {
+static inline hipError_t launch_chain96(hipStream_t s, const ChainArgs &a, bool taps = false) {
     const int k0 = a.st[0].kind, k1 = a.nstages > 1 ? a.st[1].kind : -1, k2 = a.nstages > 2 ? a.st[2].kind : -1, k3 = a.nstages > 3 ? a.st[3].kind : -1;
     if (a.dw_in) {                       // depthwise-conv prologue (kernel 31): the chains that follow the conv module's GLU
-        if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<31, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a);
-        if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<31, ST_ROWLN, ST_FFN, -1, -1>(s, a);
+        if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<31, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a, taps);
+        if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<31, ST_ROWLN, ST_FFN, -1, -1>(s, a, taps);
         return hipErrorInvalidValue;
     }
-    if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_chain96_cfg<0, ST_FFN, ST_QKV, -1, -1>(s, a);
-    if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_chain96_cfg<0, ST_ROWLN, ST_GLU, -1, -1>(s, a);
-    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<0, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a);
-    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<0, ST_ROWLN, ST_FFN, -1, -1>(s, a);
+    if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_chain96_cfg<0, ST_FFN, ST_QKV, -1, -1>(s, a, taps);
+    if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_chain96_cfg<0, ST_ROWLN, ST_GLU, -1, -1>(s, a, taps);
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_chain96_cfg<0, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV>(s, a, taps);
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_chain96_cfg<0, ST_ROWLN, ST_FFN, -1, -1>(s, a, taps);
     return hipErrorInvalidValue;
 }

@@ -46,7 +46,10 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *cocr_last_error(void) { return g_err; }
-extern "C" const char *cocr_version(void) { return "cocr-hip 0.1 (gfx950)"; }
+#ifndef COCR_SRC_HASH
+#define COCR_SRC_HASH "unknown"
+#endif
+extern "C" const char *cocr_version(void) { return "cocr-hip 0.2 (gfx950) src=" COCR_SRC_HASH; }
 
 // ------------------------------------------------------------------------------------ model
 struct HostTensor {
@@ -137,6 +140,8 @@ struct cocr_model {
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
+    float *tapbuf = nullptr;     // debug: 4 fp32 (M, D) tap targets of the chain kernels' TAPS instantiation + one bf16 (M, D)
+    size_t tapbuf_rows = 0;
     bool profile = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -240,6 +245,7 @@ static void free_workspace(cocr_model *m) {
 static void clear_taps(cocr_model *m) {
     for (auto &kv : m->taps) (void)hipFree(kv.second.first);
     m->taps.clear();
+    if (m->tapbuf) { (void)hipFree(m->tapbuf); m->tapbuf = nullptr; m->tapbuf_rows = 0; }
 }
 
 extern "C" void cocr_destroy(cocr_model *m) {
@@ -855,7 +861,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
 #endif
         constexpr int SPLITS = COCR_FO_SPLITS;
         const int Kf = F * C;
-        const bool splitk = rowln && !m->debug && (Kf % (SPLITS * (128 / (int)sizeof(T))) == 0) && D <= 256 &&
+        const bool splitk = rowln && (Kf % (SPLITS * (128 / (int)sizeof(T))) == 0) && D <= 256 &&
                             (size_t)SPLITS * M * D * 4 <= (size_t)N * T2 * F2 * C * sizeof(T);
         if (splitk) {
             float *partial = reinterpret_cast<float *>(zcur == zb ? za : zb);          // the other frontend buffer is free now
@@ -878,12 +884,34 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     }
     char nm[64];
     if constexpr (sizeof(T) == 2) {
-        if (rowln && chain_supported(D, ff, dh) && !m->debug && !m->no_chain) {
+        if (rowln && chain_supported(D, ff, dh) && !m->no_chain && !(m->debug && m->chain48)) {
             // ---- row-local chains (chain.hip.h): 4 launches per block
             const bool c96 = !m->chain48;
             const unsigned char *CW = c96 ? m->packed : B;       // chain weights: fragment-major copies or the row-major blob
             auto CWT = [&](size_t off) { return (const bf16_t *)(CW + off); };
-            auto launch = [&](const ChainArgs &a) { return c96 ? launch_chain96(s, a) : launch_chain(s, a, ff); };
+            // debug taps: the TAPS instantiation of the SAME kernels copies what never leaves the chip (or is overwritten inside the
+            // launch) into tapbuf; everything else is read from the buffers the launches leave behind
+            const bool taps = m->debug;
+            float *tp[4] = {nullptr, nullptr, nullptr, nullptr};
+            bf16_t *tap_dw = nullptr;
+            if (taps) {
+                if (m->tapbuf_rows < (size_t)M) {
+                    if (m->tapbuf) (void)hipFree(m->tapbuf);
+                    HIP_TRY(hipMalloc((void **)&m->tapbuf, (size_t)M * D * (4 * 4 + 2)));
+                    m->tapbuf_rows = (size_t)M;
+                }
+                for (int i = 0; i < 4; ++i) tp[i] = m->tapbuf + (size_t)i * M * D;
+                tap_dw = reinterpret_cast<bf16_t *>(m->tapbuf + (size_t)4 * M * D);
+            }
+            auto tapx = [&](int l, const char *what, const float *src) -> int { snprintf(nm, sizeof nm, "l%d.%s", l, what); return tap<float>(m, s, nm, src, (size_t)M * D); };
+            auto tapb = [&](int l, const char *what, const T *src, size_t n) -> int { snprintf(nm, sizeof nm, "l%d.%s", l, what); return tap<T>(m, s, nm, src, n); };
+            auto tap_qkv = [&](int l) -> int {
+                if (!taps) return COCR_OK;
+                int r;
+                if ((r = tapb(l, "q", q, m->qkv_bytes / sizeof(T))) || (r = tapb(l, "k", k, m->qkv_bytes / sizeof(T))) || (r = tapb(l, "v", v, m->qkv_bytes / sizeof(T)))) return r;
+                return COCR_OK;
+            };
+            auto launch = [&](const ChainArgs &a) { return c96 ? launch_chain96(s, a, taps) : launch_chain(s, a, ff); };
             auto base = [&]() { ChainArgs a{}; a.dump = (float *)m->dump; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
             auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
                 ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha; st.has_resid = 1;
@@ -899,8 +927,9 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 ChainArgs a = base(); a.A0 = (const bf16_t *)xn; a.nstages = 2;
                 a.st[0] = st_ffn(P.layers[0].ffn[0], P.layers[0].a_ln_g, P.layers[0].a_ln_b, -1, -1); a.st[0].store_x = 1;
                 a.st[1] = st_qkv(P.layers[0]);
-                ProfScope ps(m, s, FAM_CH_FIRST);
-                GEMM_TRY(launch(a));
+                a.st[0].tap_pre = tp[0];
+                { ProfScope ps(m, s, FAM_CH_FIRST); GEMM_TRY(launch(a)); }
+                if (taps && ((rc = tapx(0, "ffn1", tp[0])) || (rc = tap_qkv(0)))) return rc;
             }
             for (int l = 0; l < m->L; ++l) {
                 const LayerW &w = P.layers[l];
@@ -916,8 +945,10 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                     a.st[0] = st_rowln(w.wo, w.bo, 1.0f, w.c_ln_g, w.c_ln_b); a.st[0].store_x = 1;
                     ChainStage g{}; g.kind = ST_GLU; g.W = CWT(w.wpw1); g.bias = F32(w.bpw1); g.N = 2 * D; g.out = (bf16_t *)glu;
                     a.st[1] = g;
-                    ProfScope ps(m, s, FAM_CH_A);
-                    GEMM_TRY(launch(a));
+                    if (taps && (rc = tapb(l, "ctx", ctx, (size_t)M * D))) return rc;
+                    a.st[0].tap_pre = tp[0];
+                    { ProfScope ps(m, s, FAM_CH_A); GEMM_TRY(launch(a)); }
+                    if (taps && ((rc = tapx(l, "mhsa", tp[0])) || (rc = tapb(l, "glu", glu, (size_t)M * D)))) return rc;
                 }
                 const bool dw_fused = c96 && m->ksz == 31 && !m->no_dw_fuse;      // depthwise conv as the chain's prologue
                 if (!dw_fused) {
@@ -927,22 +958,31 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 }
                 {   // [depthwise conv + BN + SiLU ->] pointwise conv 2 + residual + LayerNorm -> FFN 2 (+ closing LayerNorm [+ next block's]) [-> next block's FFN 1 -> its q/k/v]
                     ChainArgs a = base(); a.A0 = (const bf16_t *)dwo;
-                    if (dw_fused) { a.dw_in = (const bf16_t *)glu; a.dw_w = F32(w.dww); a.dw_b = F32(w.dwb); }
+                    if (dw_fused) { a.dw_in = (const bf16_t *)glu; a.dw_w = F32(w.dww); a.dw_b = F32(w.dwb); a.tap_dw = tap_dw; }
                     a.st[0] = st_rowln(w.wpw2, w.bpw2, 1.0f, w.ffn[1].ln_g, w.ffn[1].ln_b);
+                    a.st[0].tap_pre = tp[0];
+                    auto tap_common = [&]() -> int {          // the stages every chain B has: depthwise output, stream after the conv module and after FFN 2
+                        int r;
+                        if ((r = tapb(l, "dw", dw_fused ? (const T *)tap_dw : (const T *)dwo, (size_t)M * D)) || (r = tapx(l, "conv", tp[0])) || (r = tapx(l, "ffn2", tp[1]))) return r;
+                        return COCR_OK;
+                    };
                     if (l + 1 < m->L) {
                         const LayerW &nx = P.layers[l + 1];
                         a.st[1] = st_ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, (long)nx.ffn[0].ln_g, (long)nx.ffn[0].ln_b);
                         a.st[2] = st_ffn(nx.ffn[0], nx.a_ln_g, nx.a_ln_b, -1, -1); a.st[2].store_x = 1;
                         a.st[3] = st_qkv(nx);
                         a.nstages = 4;
+                        a.st[1].tap_pre = tp[1]; a.st[1].tap_post = tp[2]; a.st[2].tap_pre = tp[3];
                         if (l == 5) a.stamps = m->stamps;
-                        ProfScope ps(m, s, FAM_CH_B);
-                        GEMM_TRY(launch(a));
+                        { ProfScope ps(m, s, FAM_CH_B); GEMM_TRY(launch(a)); }
+                        if (taps && ((rc = tap_common()) || (rc = tapx(l, "out", tp[2])) || (rc = tapx(l + 1, "ffn1", tp[3])) || (rc = tap_qkv(l + 1)))) return rc;
                     } else {
                         a.st[1] = st_ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, -1, -1); a.st[1].store_x = 1; a.st[1].store_xn = 1;
                         a.nstages = 2;
-                        ProfScope ps(m, s, FAM_CH_LAST);
-                        GEMM_TRY(launch(a));
+                        a.st[1].tap_pre = tp[1];
+                        { ProfScope ps(m, s, FAM_CH_LAST); GEMM_TRY(launch(a)); }
+                        // the closing LayerNorm's output exists only as the bf16 decoder operand xn on this path
+                        if (taps && ((rc = tap_common()) || (rc = tapb(l, "out", xn, (size_t)M * D)))) return rc;
                     }
                 }
             }
@@ -1081,6 +1121,7 @@ extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, in
     bool seen = false;
     for (auto &g : m->graph_seen) seen = seen || same(g);
     if (!seen || m->vtN != N || m->vtT != cocr_out_len(W, m->hp.subsampling_factor)) {     // first call: plain (also does one-time attribute / zeroing work)
+        if (m->graph_seen.size() >= 32) m->graph_seen.erase(m->graph_seen.begin());     // bounded: a caller with fresh buffers per call never captures
         m->graph_seen.push_back({lines, logits, N, W, line_dtype, s, nullptr});
         return run();
     }

@@ -59,11 +59,23 @@ def _bound(shape: Tuple[int, ...]) -> float:
     return math.sqrt(3.0 / (shape[1] * recept))
 
 
-def make_state_dict(hp: HParams, seed: int = 1234, decoder_gain: float = 1.0) -> 'OrderedDict[str, np.ndarray]':
+TEXT_OUT_PROJ_GAIN = 0.3       # style='text': attention out_proj scale
+TEXT_DW_SIGMA = 1.5            # style='text': Gaussian window (frames) on the conv module's depthwise taps
+
+
+def make_state_dict(hp: HParams, seed: int = 1234, decoder_gain: float = 1.0, style: str = 'plain') -> 'OrderedDict[str, np.ndarray]':
     """Synthetic `nn.state_dict()` (keys `encoder.*`, `decoder.*`) as float32 numpy arrays.
 
     `decoder_gain` scales decoder.weight so that random-weight logits get usable
-    top-2 margins."""
+    top-2 margins.
+
+    style='text' (the "peaked" fixtures): the same draws, then two re-scalings that make a random-weight encoder behave like
+    a trained recogniser -- LOCAL: a random attention layer is a near-uniform average over the whole line, and 12-16 of them
+    leave an encoder output that is 90 % frame-independent (top-2 margins of any decoder are then a few bf16 roundings wide).
+    `out_proj.weight` x 0.3 keeps the attention path alive at a third of its weight, and a Gaussian window (sigma 1.5 frames,
+    energy preserved) on the depthwise taps makes the conv module local.  On lines from `make_text_lines` the encoder output
+    then clusters by glyph (same-glyph distance 3.5 vs 7.6 between glyph means, measured on the reference itself) and a linear
+    decoder fitted on it (tests/golden/make_golden.py) reads the synthetic text back."""
     out: 'OrderedDict[str, np.ndarray]' = OrderedDict()
     for name, (shape, kind) in model_state_spec(hp).items():
         g = _rng(seed, name)
@@ -88,7 +100,65 @@ def make_state_dict(hp: HParams, seed: int = 1234, decoder_gain: float = 1.0) ->
             if name == 'decoder.weight':
                 w = (w * np.float32(decoder_gain)).astype(np.float32)
             out[name] = w
+    if style == 'text':
+        for name in out:
+            if name.endswith('attention.out_proj.linear.weight'):
+                out[name] = (out[name] * np.float32(TEXT_OUT_PROJ_GAIN)).astype(np.float32)
+            elif name.endswith('module.sequential.4.conv.weight'):                  # conv module depthwise taps (D, 1, k)
+                k = out[name].shape[-1]
+                win = np.exp(-0.5 * ((np.arange(k, dtype=np.float64) - k // 2) / TEXT_DW_SIGMA) ** 2)
+                win = (win * np.sqrt(k / (win ** 2).sum())).astype(np.float32)
+                out[name] = (out[name] * win).astype(np.float32)
+    elif style != 'plain':
+        raise ValueError(f'unknown weight style {style!r}')
     return out
+
+
+def text_alphabet(seed: int, alphabet: int = 24):
+    """`alphabet` distinct glyphs: (6 x 4 on/off pattern, width in pixels 24..40), drawn once per seed."""
+    g = _rng(seed, f'alphabet:{alphabet}')
+    pats = []
+    while len(pats) < alphabet:
+        p = g.uniform(0.0, 1.0, (6, 4)) > 0.5
+        if p.sum() < 6 or any((p == q[0]).all() for q in pats):
+            continue
+        pats.append((p, int(g.integers(24, 41))))
+    return [(p.astype(np.float32), w) for p, w in pats]
+
+
+def make_text_lines(n: int, height: int, width: int, seed: int = 1234, alphabet: int = 24,
+                    widths: Optional[List[int]] = None, alphabet_seed: Optional[int] = None):
+    """Synthetic TEXT lines with a ground truth: each line is a random string over `alphabet` glyphs (labels 1..alphabet, fixed
+    pattern and width per glyph, intensity 0.75-1.0), 12-20 blank pixels between glyphs, pixel noise sigma 0.03, u8-quantised
+    like `make_lines`.  Returns (image (N,1,H,W) float32, seq_lens (N,), texts: label list per line, spans: (x0, x1) pixel
+    span of every glyph).  `widths`: per-line widths (glyphs stop 8 px before a line's own end; the rest is zero padding); `alphabet_seed`: the seed the
+    glyph shapes are drawn from (default: `seed`) -- lines made by separate calls share their alphabet through it."""
+    pats = text_alphabet(seed if alphabet_seed is None else alphabet_seed, alphabet)
+    g = _rng(seed, f'text:{n}:{height}:{width}:{alphabet}')
+    img = np.zeros((n, height, width), dtype=np.float32)
+    lens = np.full((n,), width, dtype=np.int64) if widths is None else np.asarray(widths, dtype=np.int64)
+    assert lens.shape == (n,) and lens.max() <= width
+    cell_h = -(-height // 6)
+    texts, spans = [], []
+    for i in range(n):
+        x = int(g.integers(8, 20))
+        txt, sp = [], []
+        while True:
+            a = int(g.integers(0, alphabet))
+            p, w = pats[a]
+            if x + w + 8 > lens[i]:
+                break
+            img[i, :, x:x + w] = np.kron(p, np.ones((cell_h, -(-w // 4)), dtype=np.float32))[:height, :w] * np.float32(g.uniform(0.75, 1.0))
+            txt.append(a + 1)
+            sp.append((x, x + w))
+            x += w + int(g.integers(12, 21))
+        texts.append(txt)
+        spans.append(sp)
+    img = np.clip(img + g.normal(0.0, 0.03, img.shape).astype(np.float32), 0.0, 1.0)
+    u8 = np.rint(img * 255.0).astype(np.uint8)[:, None, :, :]
+    for i, w in enumerate(lens):
+        u8[i, :, :, int(w):] = 0
+    return (u8.astype(np.float32) / np.float32(255.0)), lens, texts, spans
 
 
 def make_lines(n: int, height: int, width: int, seed: int = 1234,

@@ -9,9 +9,10 @@ the last layer) frozen") and when a model is adapted to a new alphabet.  The enc
 `DecoderTrainer` says so instead of silently training less than asked.
 
 Data-parallel training: one process per GPU; each rank computes its batch's gradients, `torch.distributed.all_reduce` (backend
-"nccl" = RCCL over xGMI; two tensors, (ncls x D + ncls) x 4 bytes -- ~100 KB) sums them, every rank applies the same update: the
-replicas stay bit-identical without a weight broadcast.  The reference's loss is a SUM over lines (reduction='sum'), so gradients are
-summed, not averaged, like Lightning's DDP does for a sum-reduced loss divided by nothing."""
+"nccl" = RCCL over xGMI; two tensors, (ncls x D + ncls) x 4 bytes -- ~100 KB) combines them, every rank applies the same update: the
+replicas stay bit-identical without a weight broadcast.  The gradients are AVERAGED over the ranks: the reference trains through
+Lightning's `Trainer(devices=...)`, i.e. torch DDP, which divides the all-reduced gradients by the world size whatever the loss's
+own reduction is (each rank's loss is the sum over ITS lines, `reduction='sum'`)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -61,10 +62,11 @@ class DecoderTrainer:
 
 
 def reduce_gradients(tensors, group=None) -> None:
-    """Sum of each gradient tensor over the ranks, in place: ONE collective on a flat bucket (the tensors are small; two launches of a
-    ring all-reduce would cost two latencies over xGMI)."""
+    """Mean of each gradient tensor over the ranks (torch DDP's semantics), in place: ONE collective on a flat bucket (the tensors
+    are small; two launches of a ring all-reduce would cost two latencies over xGMI).  Sum + division: gloo has no AVG op."""
     flat = torch.cat([t.reshape(-1) for t in tensors])
     torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
+    flat.div_(torch.distributed.get_world_size(group))
     off = 0
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].view_as(t))

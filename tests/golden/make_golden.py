@@ -128,9 +128,137 @@ def run_case(meta, name, hp, seed, n, W, widths=None, with_taps=False, head=None
     return state, enc, dec
 
 
+# ------------------------------------------------------------------------------------------------ "text" (peaked) fixtures
+def frame_targets(T, texts, spans, edge=2.0):
+    """Per-frame training target of a text line: output frame t sees pixels around 4t + 1.5 (two stride-2 stages); the glyph's
+    label where that pixel lies inside the glyph (`edge` px from its ends), blank (0) everywhere else."""
+    px = 4.0 * np.arange(T) + 1.5
+    tgt = np.zeros((T,), dtype=np.int64)
+    for a, (x0, x1) in zip(texts, spans):
+        tgt[(px >= x0 + edge) & (px < x1 - edge)] = a
+    return tgt
+
+
+def fit_text_decoder(frames, targets, ncls, used, iters=2000, wd=1e-4, seed=0):
+    """Multinomial logistic regression (Adam, full batch) of the per-frame targets on the REFERENCE's encoder output `frames`
+    (M, D): the decoder a training run would have produced for this synthetic text, fitted on this very batch.  Classes >= `used`
+    get zero weights and bias -30 (never win).  Returns decoder.weight (ncls, D), decoder.bias (ncls) as float32 numpy."""
+    torch.manual_seed(seed)
+    X = torch.from_numpy(frames)
+    tg = torch.from_numpy(targets)
+    mu = X.mean(0)
+    Xc = X - mu
+    W = torch.zeros(ncls, X.shape[1], requires_grad=True)
+    b = torch.zeros(ncls, requires_grad=True)
+    live = torch.zeros(ncls, dtype=torch.bool)
+    live[:used] = True
+    opt = torch.optim.Adam([W, b], lr=0.02)
+    for _ in range(iters):
+        opt.zero_grad()
+        lg = (Xc @ W.t() + b).masked_fill(~live, -30.0)
+        loss = torch.nn.functional.cross_entropy(lg, tg) + wd * (W ** 2).sum()
+        loss.backward()
+        opt.step()
+    with torch.no_grad():
+        Wf = W.detach().clone()
+        Wf[~live] = 0.0
+        bf = (b - Wf @ mu).detach().clone()
+        bf[~live] = -30.0
+    return Wf.numpy().astype(np.float32), bf.numpy().astype(np.float32)
+
+
+def collapse(labels):
+    """CTC greedy collapse of a frame-label array: merge repeats, drop blanks."""
+    out, prev = [], -1
+    for v in labels:
+        v = int(v)
+        if v != prev and v != 0:
+            out.append(v)
+        prev = v
+    return out
+
+
+def ragged(seqs, dtype=np.int16):
+    return (np.asarray([x for s in seqs for x in s], dtype=dtype), np.asarray([len(s) for s in seqs], dtype=np.int32))
+
+
+def run_text_case(meta, name, hp, seed, widths, batch_size, edge, alphabet=24, head=2):
+    """A fixture with a ground truth: `len(widths)` text lines (conformer_ocr_amd.synth.make_text_lines, one seed per line),
+    grouped into fixed-edge width buckets exactly like conformer_ocr_amd.evaluate.recognize does (edge 0: one batch, no
+    bucketing), 'text'-style weights, the decoder fitted on the reference's own encoder output; stores the fitted decoder, the
+    reference's per-frame labels / top-2 margins / greedy label strings per line and the ground-truth strings."""
+    from conformer_ocr_amd.evaluate import collate, make_batches
+    n = len(widths)
+    lines, texts, spans = [], [], []
+    for i, w in enumerate(widths):
+        im, _, tx, sp = synth.make_text_lines(1, hp.height, int(w), seed=seed + 1000 + i, alphabet=alphabet, alphabet_seed=seed)
+        lines.append(im[0, 0]); texts.append(tx[0]); spans.append(sp[0])
+    batches = make_batches(list(widths), batch_size, edge) if edge else [(int(max(widths)), list(range(n)))]
+    state = synth.make_state_dict(hp, seed=seed, decoder_gain=1.0, style='text')
+    enc, _ = build_reference(hp, state)
+    eos, olens = {}, {}
+    with torch.no_grad():
+        for bw, idx in batches:
+            im, lens = collate(lines, idx, bw)
+            eo, el = enc(im.squeeze(1).transpose(1, 2), lens)                     # pred.py:119-120
+            for k, i in enumerate(idx):
+                eos[i] = eo[k].numpy()
+                olens[i] = int(el[k])
+    # decoder fitted on the frames of every line inside its own length
+    fr = np.concatenate([eos[i][:olens[i]] for i in range(n)])
+    tg = np.concatenate([frame_targets(olens[i], texts[i], spans[i]) for i in range(n)])
+    W, b = fit_text_decoder(fr, tg, hp.num_classes, alphabet + 1)
+    state['decoder.weight'], state['decoder.bias'] = W, b
+    dec = torch.nn.Linear(hp.encoder_dim, hp.num_classes)
+    dec.load_state_dict({'weight': torch.from_numpy(W), 'bias': torch.from_numpy(b)})
+    labels, margs, strings, heads = [], [], [], []
+    with torch.no_grad():
+        for i in range(n):
+            lg = dec(torch.from_numpy(eos[i])).numpy()                            # pred.py:121 (all frames of the padded row)
+            v = lg[:olens[i]]
+            labels.append(np.argmax(v, -1)); margs.append(margins(v)); strings.append(collapse(labels[-1]))
+            if i < head:
+                heads.append(lg)
+    lab_flat, lab_len = ragged(labels)
+    txt_flat, txt_len = ragged(texts)
+    str_flat, str_len = ragged(strings)
+    out = {'decoder_weight': W, 'decoder_bias': b, 'out_lens': np.asarray([olens[i] for i in range(n)], dtype=np.int32),
+           'labels': lab_flat, 'margins': np.concatenate(margs).astype(np.float16), 'texts': txt_flat, 'text_lens': txt_len,
+           'ref_strings': str_flat, 'ref_string_lens': str_len}
+    for i, h in enumerate(heads):
+        out[f'logits_line{i}'] = h.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    allm = np.concatenate(margs)
+    exact = sum(strings[i] == texts[i] for i in range(n))
+    from conformer_ocr_amd.evaluate import edit_distance
+    cer = sum(edit_distance(strings[i], texts[i]) for i in range(n)) / max(1, sum(len(t) for t in texts))
+    meta[name] = {'hparams': hp.as_dict(), 'seed': seed, 'style': 'text', 'alphabet': alphabet, 'widths': [int(w) for w in widths],
+                  'batch_size': batch_size, 'edge': edge, 'frames': int(allm.size), 'frac_margin_gt_1': float((allm > 1.0).mean()),
+                  'margin_q01': float(np.quantile(allm, 0.01)), 'reference_lines_equal_to_truth': int(exact),
+                  'reference_cer_vs_truth': float(cer), 'blank_share': float((lab_flat == 0).mean())}
+    print(name, {k: meta[name][k] for k in ('frames', 'frac_margin_gt_1', 'margin_q01', 'reference_lines_equal_to_truth', 'reference_cer_vs_truth')})
+    return state
+
+
+def text_cases(meta):
+    # cfg2_text: the metric's configuration and batch (32 lines of 96x1200), text lines + fitted decoder
+    run_text_case(meta, 'cfg2_text', synth.hparams('cfg2'), 2001, [1200] * 32, 32, 0)
+    # cfg4_text: BASELINE configs[3] -- wide conformer, widths U{400..2400} step 8, bucket edge 200, batches of <= 8
+    g = np.random.Generator(np.random.PCG64(4004))
+    widths = (400 + 8 * g.integers(0, 251, 24)).tolist()
+    run_text_case(meta, 'cfg4_text', synth.hparams('cfg4'), 2004, widths, 8, 200)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'text':       # only the text fixtures, merged into the existing meta.json
+        with open(os.path.join(HERE, 'meta.json')) as fp:
+            meta = json.load(fp)
+        text_cases(meta)
+        with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
+            json.dump(meta, fp, indent=1)
+        return
     meta = {}
     # tiny: full per-stage taps, padding leak exercised (widths 64/37/50 padded to 64)
     hp = synth.hparams('tiny')
@@ -154,6 +282,7 @@ def main():
     # cfg4 (wide conformer D=512, L=16, h=8): 3 lines of bucketed widths padded to 1400
     hp4 = synth.hparams('cfg4')
     run_case(meta, 'cfg4', hp4, 1238, 3, 1400, widths=[1400, 1256, 1208], head=1)
+    text_cases(meta)
     with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
         json.dump(meta, fp, indent=1)
     for f in sorted(os.listdir(HERE)):

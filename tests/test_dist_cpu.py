@@ -100,8 +100,8 @@ def _grad_worker(rank, world, port, q):
 
 @pytest.mark.timeout(120)
 def test_world_size_2_gradient_all_reduce():
-    """Data-parallel output-layer training (conformer_ocr_amd/train.py): the two decoder gradients are SUMMED over ranks in one
-    flat bucket (the reference's loss is a sum over lines), every rank ends with the same tensors."""
+    """Data-parallel output-layer training (conformer_ocr_amd/train.py): the two decoder gradients are AVERAGED over ranks in one
+    flat bucket (torch DDP's semantics, what the reference's Lightning Trainer applies), every rank ends with the same tensors."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -116,7 +116,7 @@ def test_world_size_2_gradient_all_reduce():
     gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
     ws = [torch.randn((7, 16), generator=g) for g in gens]
     bs = [torch.randn((7,), generator=g) for g in gens]
-    np.testing.assert_allclose(res[0][1], (ws[0] + ws[1]).numpy(), rtol=1e-6)
-    np.testing.assert_allclose(res[0][2], (bs[0] + bs[1]).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(res[0][1], ((ws[0] + ws[1]) / 2).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(res[0][2], ((bs[0] + bs[1]) / 2).numpy(), rtol=1e-6)
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and want_w.shape == (7, 16)
     assert res[0][3] == res[1][3] == [7.0, 210.0, 4.5]                             # validation counters: summed, identical on both ranks
