@@ -2,17 +2,27 @@
 """
 bench.py -- throughput of the recognition hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg4]
 
-A "step" is one pass of the hot path over one batch: 32 synthetic 96x1200 lines (BASELINE.json
-configs[1], the configuration the metric is quoted on) -> conformer encoder (D=256, 12 blocks, bf16
-operands) -> decoder -> CTC greedy labels, through the C ABI of libcocr_hip.so.  Inputs are resident
-in HBM when the timed region starts.  With N > 1 every rank owns one GPU, receives the packed weights
-by one RCCL broadcast and processes its own independent batches (no data-path collective): weak scaling.
+A "step" is one pass of the hot path over one batch, through the C ABI of libcocr_hip.so:
+line batch resident in HBM -> conformer encoder (bf16 operands) -> decoder -> CTC greedy label records.
 
-Rank 0 prints ONE JSON line: metric/value (whole-job lines/s), the roofline of the dominant kernel
-(measured live with HIP events on the forward's stream), and the CPU baseline (the oracle on the host
-cores, bounded sample).
+  --config cfg2 (default; BASELINE.json configs[1], the configuration the metric is quoted on): 32 synthetic 96x1200 lines,
+      D=256, 12 blocks.  The batch is the `cfg2_text` fixture's (tests/golden): text lines with a ground truth and a decoder
+      fitted on the reference's own encoder output, so that the CER beside the throughput means something.
+  --config cfg4 (configs[3]): D=512, 16 blocks, `--lines` lines of widths U{400..2400} step 8 in fixed 200-px buckets,
+      batches of <= `--batch` lines padded to their bucket's width; a step is the next batch of that queue.
+
+With N > 1 every rank owns one GPU, receives the packed weights by one RCCL broadcast and processes its own independent
+batches (no data-path collective): weak scaling.  Rank 0 prints ONE JSON line:
+
+  value                 whole-job lines/s, `--streams` (4) batches in flight per GPU, inputs resident in HBM
+  value_streams1        the same loop with ONE batch in flight (what a single caller thread without its own streams sees)
+  predict_string        `PytorchRecognitionModel.predict_string` (the drop-in surface) called with a FRESH input tensor per call
+  ingest                u8 lines from pinned host memory, double-buffered host->device copies inside the loop (PCIe-inclusive)
+  cer_vs_reference      CER of the bf16 strings against the reference's fp32 greedy strings (fixture), cer_vs_truth: against the text
+  roofline              the dominant kernel: algorithmic FLOP per launch / HIP-event duration measured live on the forward's stream
+  cpu_baseline          the CPU oracle (fp32 restatement of the reference) on the host cores, bounded sample
 """
 import argparse
 import json
@@ -33,10 +43,13 @@ sys.path.insert(0, ROOT)
 
 from conformer_ocr_amd import synth  # noqa: E402
 from conformer_ocr_amd.engine import HipRecognizer  # noqa: E402
-from conformer_ocr_amd.spec import flops_per_line, out_len  # noqa: E402
+from conformer_ocr_amd.evaluate import ErrorRate, collate, make_batches  # noqa: E402
+from conformer_ocr_amd.spec import HParams, flops_per_line, out_len  # noqa: E402
 
+METRIC = 'text lines/sec (whole node) + CER vs reference, 96×1200 bf16 batch'      # BASELINE.json `metric`, verbatim
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}     # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 def kernel_table(hp, n, w, dtype):
@@ -44,7 +57,7 @@ def kernel_table(hp, n, w, dtype):
     (bound, flops or bytes per launch).  GEMMs: 2*M*N*K flop.  HBM-bound kernels: one read + one write
     of their operand."""
     es = 2 if dtype == 'bf16' else 4
-    D, C, ff, h = hp.encoder_dim, hp.subsampling_conv_channels, hp.feed_forward_expansion_factor * hp.encoder_dim, hp.num_attention_heads
+    D, C, ff = hp.encoder_dim, hp.subsampling_conv_channels, hp.feed_forward_expansion_factor * hp.encoder_dim
     T1, T, F = out_len(w, 1), out_len(w, 2), hp.out_feats
     M = n * T
     ncls = hp.num_classes
@@ -73,30 +86,69 @@ def kernel_table(hp, n, w, dtype):
 
 
 def cus_occupied(family, rows):
-    """CUs a launch of `family` can occupy (MI355X: 256): the 96-row chain kernels run one workgroup per CU."""
+    """CUs a launch of `family` can occupy (MI355X: 256): the row-block chain kernels run one workgroup per CU."""
     if family.startswith('chain_') and rows >= 4800:
         return min(256, -(-rows // 96))
     return 256
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (collected offline with
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` on this bench command; tools/summarize_rocprof.py), or None."""
+PROFILE_KERNEL_NAMES = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu',
+                        'frontend_conv12': 'frontend_conv12', 'frontend_fused': 'frontend96_kernel',
+                        'chain_pw2_ffn_ffn_qkv': 'chain96_kernel<6, 31, 0, 1, 1, 3', 'chain_attn_out_glu': 'chain96_kernel<6, 0, 0, 2, -1, -1',
+                        'chain_ffn_qkv': 'chain96_kernel<6, 0, 1, 3, -1, -1', 'chain_pw2_ffn': 'chain96_kernel<6, 31, 0, 1, -1, -1'}
+
+
+def pmc_traffic(family, live_avg_ms):
+    """HBM bytes per launch of a kernel family from the NEWEST committed rocprofv3 PMC summary (PMC counters cannot be read from
+    inside the process: they come from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this bench command, condensed
+    by tools/summarize_rocprof.py).  Returned with the file it came from and a staleness flag: the kernel's average duration in
+    the kernel-trace summary of the same round against the duration measured live in this run."""
     import csv
     import glob
-    names = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12',
-             'frontend_fused': 'frontend96_kernel',
-             'chain_pw2_ffn_ffn_qkv': 'chain96_kernel<6, 31, 0, 1, 1, 3>', 'chain_attn_out_glu': 'chain96_kernel<6, 0, 0, 2, -1, -1>',
-             'chain_ffn_qkv': 'chain96_kernel<6, 0, 1, 3, -1, -1>', 'chain_pw2_ffn': 'chain96_kernel<6, 31, 0, 1, -1, -1>'}
-    if family not in names:
-        return None
+    name = PROFILE_KERNEL_NAMES.get(family)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.csv')))
-    if not files:
+    if name is None or not files:
+        return None, None
+    f = files[-1]
+    traffic = None
+    for r in csv.DictReader(open(f)):
+        if name in r['kernel']:
+            traffic = int(r['hbm_bytes_per_launch(2*fetch+write)'])
+            break
+    if traffic is None:
+        return None, {'file': os.path.relpath(f, ROOT), 'note': f'no row for {name}'}
+    info = {'file': os.path.relpath(f, ROOT)}
+    stats = f.replace('_pmc_traffic.csv', '_kernel_stats.csv')
+    if os.path.exists(stats):
+        for r in csv.DictReader(open(stats)):
+            if name in r['kernel']:
+                prof_ms = float(r['avg_ns']) * 1e-6
+                info.update(profile_avg_ms=round(prof_ms, 5), stale=bool(abs(prof_ms - live_avg_ms) > 0.15 * live_avg_ms))
+                break
+    return traffic, info
+
+
+def load_text_fixture(name):
+    """A "text" fixture of tests/golden (make_golden.py run_text_case): hp, weights (seeded 'text'-style encoder + the fitted
+    decoder stored in the npz), lines, ground-truth label strings, the reference's greedy label strings.  None if absent."""
+    meta_p, npz_p = os.path.join(GOLDEN, 'meta.json'), os.path.join(GOLDEN, name + '.npz')
+    if not (os.path.exists(meta_p) and os.path.exists(npz_p)):
         return None
-    for r in csv.DictReader(open(files[-1])):
-        if names[family] in r['kernel']:
-            return int(r['hbm_bytes_per_launch(2*fetch+write)'])
-    return None
+    m = json.load(open(meta_p)).get(name)
+    if m is None:
+        return None
+    g = np.load(npz_p)
+    hp = HParams(**m['hparams'])
+    state = synth.make_state_dict(hp, seed=m['seed'], decoder_gain=1.0, style=m['style'])
+    state['decoder.weight'], state['decoder.bias'] = g['decoder_weight'], g['decoder_bias']
+    lines = [synth.make_text_lines(1, hp.height, w, seed=m['seed'] + 1000 + i, alphabet=m['alphabet'], alphabet_seed=m['seed'])[0][0, 0]
+             for i, w in enumerate(m['widths'])]
+
+    def unrag(flat, lens):
+        o = np.concatenate([[0], np.cumsum(lens)])
+        return [flat[o[i]:o[i + 1]].astype(np.int64).tolist() for i in range(len(lens))]
+    return {'hp': hp, 'state': state, 'lines': lines, 'texts': unrag(g['texts'], g['text_lens']), 'meta': m,
+            'ref_strings': unrag(g['ref_strings'], g['ref_string_lens'])}
 
 
 def cpu_baseline(hp, state, width, sample_lines):
@@ -128,6 +180,10 @@ def cpu_baseline(hp, state, width, sample_lines):
             'sample': f'{reps} x {sample_lines} lines of 96x{width}, fp32 torch-CPU oracle forward + greedy decode, {dt:.1f} s'}
 
 
+def strings_of(records):
+    return [[int(r[0]) for r in line] for line in records]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -135,12 +191,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--width', type=int, default=1200)
-    ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--lines', type=int, default=320, help='cfg4: lines in the mixed-width queue of one rank')
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg4', 'cfg1'])
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the streams1 / predict_string / ingest legs (profiling runs)')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a captured hipGraph')
-    ap.add_argument('--stagger-us', type=float, default=0.0, help='host-side offset between the first batches of a run (multi-stream only)')
     ap.add_argument('--streams', type=int, default=4, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL at communicator creation) go to stderr
@@ -152,23 +209,27 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     use_dist = 'RANK' in os.environ          # launched by torch.distributed.run (any world size, also 1)
+    if world != args.gpus:                   # a line for N GPUs is only printed by a job that runs on N ranks
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}\n')
+        sys.exit(2)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
-    hp = synth.hparams(args.config)
+    # ---- model: the text fixture's weights when the fixture is there (same FLOPs as any other weights; the CER then has a meaning)
+    fix = load_text_fixture({'cfg2': 'cfg2_text', 'cfg4': 'cfg4_text'}.get(args.config, ''))
+    hp = fix['hp'] if fix else synth.hparams(args.config)
     S = max(1, args.streams)
     engines = [HipRecognizer(hp, dev, args.dtype) for _ in range(S)]
     eng = engines[0]
     state = None
     if rank == 0:
-        state = synth.make_state_dict(hp, seed=1236, decoder_gain=8.0)
+        state = fix['state'] if fix else synth.make_state_dict(hp, seed=1236, decoder_gain=8.0)
         for e in engines:
             e.load_state(state)
             e.finalize()
@@ -180,74 +241,189 @@ def main():
         for e in engines:
             broadcast_weights(e, src=0)
 
-    # per-rank independent synthetic batches, resident in HBM (float32 (N,H,W), what the reference's loader hands over)
-    img, lens = synth.make_lines(args.batch, hp.height, args.width, seed=1000 + rank)
-    x = torch.from_numpy(img[:, 0]).to(dev)
-    lens32 = lens.astype(np.int32)
+    # ---- per-rank independent batches, resident in HBM (float32 (N,H,W): what the reference's loader hands over, cli/test.py:189)
+    if args.config == 'cfg4':
+        g = np.random.Generator(np.random.PCG64(5000 + rank))
+        widths = (400 + 8 * g.integers(0, 251, args.lines)).tolist()
+        lines = [synth.make_text_lines(1, hp.height, int(w), seed=9000 + 1000 * rank + i, alphabet_seed=fix['meta']['seed'] if fix else 1)[0][0, 0]
+                 for i, w in enumerate(widths)]
+        plan = make_batches(widths, args.batch, 200)
+        workload = f'cfg4: conformer D={hp.encoder_dim} L={hp.num_encoder_layers} heads={hp.num_attention_heads}, {args.lines} lines per GPU of widths ' \
+                   f'U{{400..2400}} step 8 in 200-px buckets, batches of <= {args.batch} padded to the bucket width, forward + CTC greedy'
+    else:
+        if fix and rank == 0 and args.batch == len(fix['lines']) and args.width == 1200:
+            lines = fix['lines']
+        else:
+            lines = [synth.make_text_lines(1, hp.height, args.width, seed=7000 + 100 * rank + i, alphabet_seed=fix['meta']['seed'] if fix else 1)[0][0, 0]
+                     for i in range(args.batch)]
+        widths = [args.width] * args.batch
+        plan = [(args.width, list(range(args.batch)))]
+        workload = f'{args.config}: conformer D={hp.encoder_dim} L={hp.num_encoder_layers} heads={hp.num_attention_heads} ' \
+                   f'sub_ch={hp.subsampling_conv_channels}, batch {args.batch} x 96x{args.width} per GPU, forward + CTC greedy'
+    batches = []
+    for bw, idx in plan:
+        im, lens = collate(lines, idx, bw)
+        batches.append({'x': im[:, 0].contiguous().to(dev), 'lens': lens.numpy().astype(np.int32), 'idx': idx, 'w': bw, 'n': len(idx)})
+    NB = len(batches)
+    lines_per_cycle = sum(b['n'] for b in batches)
+    max_n, max_w = max(b['n'] for b in batches), max(b['w'] for b in batches)
     for e in engines:
-        e.reserve(args.batch, args.width)
+        e.reserve(max_n, max_w)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
-    T_out = eng.out_len(args.width)
-    outs = [torch.empty((args.batch, T_out, hp.num_classes), dtype=torch.float32, device=dev) for _ in range(S)]
+    outs = [[torch.empty((b['n'], eng.out_len(b['w']), hp.num_classes), dtype=torch.float32, device=dev) for b in batches] for _ in range(S)]
+    use_graph = not args.no_graph and NB <= 4            # the library keeps 16 captured graphs per model (main loop + 2 staging buffers each)
     for e in engines:
-        e.set_graph(not args.no_graph)
+        e.set_graph(use_graph)
 
-    stagger_s = args.stagger_us * 1e-6 if S > 1 else 0.0
-
-    def run_steps(n):
-        """n steps; step i is enqueued on stream i % S (forward + greedy decode + D2H of the label records) and its
-        records are collected S steps later, so S independent batches overlap on the GPU."""
-        pending, recs = [], None
+    def run_steps(n, nstreams, first=0):
+        """n steps; step i runs batch (first + i) % NB on stream i % nstreams (forward + greedy decode; the label records land in
+        pinned host memory) and is collected nstreams steps later, so nstreams independent batches overlap on the GPU.
+        Returns (lines processed, records of the last collected step)."""
+        pending, recs, done = [], None, 0
         for i in range(n):
-            e = engines[i % S]
-            with torch.cuda.stream(streams[i % S]):
-                logits, out_lens = e.forward(x, lens32, out=outs[i % S])
-                pending.append((e, e.ctc_greedy_async(logits, out_lens)))
-            if i < S - 1 and stagger_s > 0:
-                # the first S batches would start in lockstep (all frontends, then all attention kernels, ... at the same time:
-                # measured 2x the steady-state time for that first group); offset them by a fraction of a step like the steady state
-                t_end = time.perf_counter() + stagger_s
-                while time.perf_counter() < t_end:
-                    pass
-            if len(pending) >= S:
-                pe, h = pending.pop(0)
+            k, b = i % nstreams, (first + i) % NB
+            e = engines[k]
+            with torch.cuda.stream(streams[k]):
+                logits, out_lens = e.forward(batches[b]['x'], batches[b]['lens'], out=outs[k][b])
+                pending.append((e, e.ctc_greedy_async(logits, out_lens), b))
+            if len(pending) >= nstreams:
+                pe, h, pb = pending.pop(0)
                 recs = pe.collect(h)
-        for pe, h in pending:
+                done += batches[pb]['n']
+        for pe, h, pb in pending:
             recs = pe.collect(h)
-        return recs
-
-    def step():
-        logits, out_lens = eng.forward(x, lens32)
-        return eng.ctc_greedy(logits, out_lens)
+            done += batches[pb]['n']
+        return done, recs
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run_steps(args.warmup)
+    # pre-warm: every (engine, batch) pair is called three times -- plain (one-time attribute / workspace work), captured into a
+    # hipGraph, replayed -- so that no capture or instantiation lands in the timed region whatever --steps / --warmup are
+    for k in range(S):
+        with torch.cuda.stream(streams[k]):
+            for b in range(NB):
+                for _ in range(3):
+                    lg, ol = engines[k].forward(batches[b]['x'], batches[b]['lens'], out=outs[k][b])
+                    engines[k].collect(engines[k].ctc_greedy_async(lg, ol))
+    torch.cuda.synchronize(dev)
+
+    run_steps(args.warmup, S)
     fence()
     t0 = time.perf_counter()
-    recs = run_steps(args.steps)
+    done, recs = run_steps(args.steps, S)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    lines_total = args.batch * args.steps * world
+        t = torch.tensor([dt, float(done)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, lines_total = float(tmax[0].item()), float(t[1].item())
+    else:
+        lines_total = float(done)
     value = lines_total / dt
+
+    extra = {}
+    if rank == 0 and not args.no_extra_legs:
+        # ---- one batch in flight (a caller without streams of its own)
+        torch.cuda.synchronize(dev)
+        run_steps(min(args.warmup, 5), 1)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        d1, _ = run_steps(args.steps, 1)
+        torch.cuda.synchronize(dev)
+        extra['value_streams1'] = round(d1 / (time.perf_counter() - t1), 2)
+
+        # ---- the drop-in surface: PytorchRecognitionModel.predict_string, a fresh input tensor per call, no graph replay
+        from conformer_ocr_amd.codec import ascii_codec
+        from conformer_ocr_amd.pred import PytorchRecognitionModel
+        net = PytorchRecognitionModel(**hp.as_dict(), input_dropout_p=0.1, feed_forward_dropout_p=0.1, attention_dropout_p=0.1,
+                                      conv_dropout_p=0.1, codec=ascii_codec(hp.num_classes), compute_dtype=args.dtype)
+        net.nn.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        net = net.to(dev).eval()
+        b0 = batches[0]
+        lens_t = torch.from_numpy(b0['lens'].astype(np.int64))
+        net.predict_string(b0['x'].unsqueeze(1).clone(), lens_t)
+        torch.cuda.synchronize(dev)
+        reps = max(10, min(args.steps, 100))
+        t2 = time.perf_counter()
+        for _ in range(reps):
+            strs = net.predict_string(b0['x'].unsqueeze(1).clone(), lens_t)       # .clone(): a new device buffer per call, like a loader's batch
+        torch.cuda.synchronize(dev)
+        extra['predict_string'] = {'value': round(reps * b0['n'] / (time.perf_counter() - t2), 2), 'unit': 'lines/s', 'calls': reps,
+                                   'what': 'net.predict_string(fresh (N,1,H,W) device tensor, lens) one call at a time: forward + greedy decode + '
+                                           'read-back + codec, no hipGraph, no caller-side streams'}
+        del net
+
+        # ---- ingest: u8 lines from pinned host memory, double-buffered host->device copy inside the loop (PCIe-inclusive; never `value`)
+        hosts = [torch.from_numpy(np.rint(b['x'].cpu().numpy() * 255.0).astype(np.uint8)).pin_memory() for b in batches]
+        stage = [[torch.empty_like(hosts[b], device=dev) for b in range(NB)] for _ in range(2 * S)]
+        copy_streams = [torch.cuda.Stream(dev) for _ in range(S)]
+
+        def ingest_steps(n):
+            pending, cnt = [], 0
+            for i in range(n):
+                k, b, slot = i % S, i % NB, i % (2 * S)
+                with torch.cuda.stream(copy_streams[k]):
+                    stage[slot][b].copy_(hosts[b], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_streams[k])
+                with torch.cuda.stream(streams[k]):
+                    streams[k].wait_event(ev)
+                    lg, ol = engines[k].forward(stage[slot][b], batches[b]['lens'], out=outs[k][b])
+                    pending.append((engines[k], engines[k].ctc_greedy_async(lg, ol), b))
+                if len(pending) >= S:
+                    pe, h, pb = pending.pop(0)
+                    pe.collect(h)
+                    cnt += batches[pb]['n']
+            for pe, h, pb in pending:
+                pe.collect(h)
+                cnt += batches[pb]['n']
+            return cnt
+        ingest_steps(8 * S * min(NB, 3))
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        d3 = ingest_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        extra['ingest'] = {'value': round(d3 / (time.perf_counter() - t3), 2), 'unit': 'lines/s',
+                           'what': f'u8 (N,H,W) batches copied from pinned host memory inside the loop ({S} copy streams, 2 staging buffers per '
+                                   'stream), forward ingests u8 directly'}
+
+    # ---- CER (outside the timed region): the compute dtype's greedy strings on the fixture against the reference's fp32 greedy
+    # strings of the same padded batches (tests/golden) and against the ground-truth text
+    cer = None
+    if rank == 0 and fix:
+        fb = [(max(fix['meta']['widths']), list(range(len(fix['lines']))))] if not fix['meta']['edge'] else \
+            make_batches(fix['meta']['widths'], fix['meta']['batch_size'], fix['meta']['edge'])
+        got = {}
+        for bw, idx in fb:
+            im, lens = collate(fix['lines'], idx, bw)
+            lg, ol = eng.forward(im[:, 0].contiguous().to(dev), lens.numpy())
+            for i, r in zip(idx, strings_of(eng.ctc_greedy(lg, ol))):
+                got[i] = r
+        n = len(fix['lines'])
+        c_ref, c_truth = ErrorRate(), ErrorRate()
+        c_ref.update([got[i] for i in range(n)], fix['ref_strings'])
+        c_truth.update([got[i] for i in range(n)], fix['texts'])
+        cer = {'cer_vs_reference': c_ref.compute(), 'cer_vs_truth': c_truth.compute(), 'lines': n, 'characters': c_truth.total,
+               'lines_identical_to_reference': sum(got[i] == fix['ref_strings'][i] for i in range(n)),
+               'fixture': f"tests/golden/{'cfg2_text' if args.config != 'cfg4' else 'cfg4_text'}.npz (reference fp32 greedy strings of the same padded batches)"}
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the forward's stream
     roof, kernels = None, {}
     if rank == 0 and args.profile_steps > 0:
+        pb = max(range(NB), key=lambda b: batches[b]['n'] * batches[b]['w'])          # the heaviest batch of the queue
         torch.cuda.synchronize(dev)
         eng.profile(True)
         for _ in range(args.profile_steps):
-            step()
+            lg, ol = eng.forward(batches[pb]['x'], batches[pb]['lens'])
+            eng.ctc_greedy(lg, ol)
         prof = eng.profile_read()
         eng.profile(False)
-        table = kernel_table(hp, args.batch, args.width, args.dtype)
+        table = kernel_table(hp, batches[pb]['n'], batches[pb]['w'], args.dtype)
         # an empty event pair (one per forward) measures what a bracket costs by itself; it is subtracted from every average so
         # that these numbers are dispatch durations, comparable with `rocprofv3 --kernel-trace --stats` (profiles/)
         ovh = prof.pop('event_pair_overhead', (0.0, 0))[0]
@@ -265,29 +441,37 @@ def main():
             kernels[name] = rec
         dom = max(kernels, key=lambda k: kernels[k]['share'])
         d = kernels[dom]
+        rows = batches[pb]['n'] * eng.out_len(batches[pb]['w'])
+        traffic, tinfo = pmc_traffic(dom, d['avg_ms'])
         roof = {'kernel': dom, 'bound': 'hbm' if d['bound'] == 'hbm' else 'mfma', 'achieved': d['achieved'], 'peak': d['peak'],
-                'unit': d['unit'], 'frac': d['frac'], 'traffic': pmc_traffic(dom), 'avg_ms': d['avg_ms'], 'share_of_step': d['share'],
+                'unit': d['unit'], 'frac': d['frac'], 'traffic': traffic, 'traffic_profile': tinfo, 'avg_ms': d['avg_ms'], 'share_of_step': d['share'],
                 'algorithmic_per_launch': table[dom][1], 'event_pair_overhead_ms': round(ovh, 5),
-                # the 96-row chain kernels launch ceil(rows / 96) workgroups of one per CU: `frac` prices them against the WHOLE chip
-                'cus_occupied': cus_occupied(dom, args.batch * T_out), 'frac_of_occupied_cus': round(d['frac'] * 256.0 / cus_occupied(dom, args.batch * T_out), 5),
-                'traffic_source': 'profiles/*_pmc_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                'separate passes, 2*FETCH+WRITE bytes per launch)'}
+                'profiled_batch': {'lines': batches[pb]['n'], 'width': batches[pb]['w']},
+                # the row-block chain kernels launch ceil(rows / 96) workgroups of one per CU: `frac` prices them against the WHOLE chip
+                'cus_occupied': cus_occupied(dom, rows), 'frac_of_occupied_cus': round(d['frac'] * 256.0 / cus_occupied(dom, rows), 5),
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command, 2*FETCH+WRITE bytes per launch '
+                                  '(newest profiles/*_pmc_traffic.csv; `traffic_profile.stale` compares that round\'s kernel duration with this run\'s)'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(hp, state, args.width, sample_lines=args.batch)
+        cpu = cpu_baseline(hp, state, max_w if args.config != 'cfg4' else 1400, sample_lines=min(32, args.batch) if args.config != 'cfg4' else 8)
 
     if rank == 0:
-        gflop = flops_per_line(hp, args.width) / 1e9
+        per_line = [flops_per_line(hp, w) for w in widths]
+        padded = sum(flops_per_line(hp, b['w']) * b['n'] for b in batches) / lines_per_cycle
+        gflop = float(np.mean(per_line)) / 1e9
         out = {
-            'metric': 'text lines/sec (whole node), 96x1200 bf16 batch', 'value': round(value, 2), 'unit': 'lines/s',
+            'metric': METRIC, 'value': round(value, 2), 'unit': 'lines/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'{args.config}: conformer D={hp.encoder_dim} L={hp.num_encoder_layers} heads={hp.num_attention_heads} '
-                                   f'sub_ch={hp.subsampling_conv_channels}, batch {args.batch} x 96x{args.width} per GPU, '
-                                   f'forward + CTC greedy', 'lines_per_step_per_gpu': args.batch, 'gflop_per_line': round(gflop, 3),
-                       'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast', 'streams_per_gpu': S},
+            'config': {'workload': workload, 'lines_per_step_per_gpu': round(lines_per_cycle / NB, 2), 'batches_in_queue': NB,
+                       'gflop_per_line': round(gflop, 3), 'gflop_per_line_padded': round(padded / 1e9, 3),
+                       'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast', 'streams_per_gpu': S,
+                       'hipgraph_replay': bool(use_graph)},
             'achieved_tflops_whole_path': round(value * gflop / 1e3, 2),
+            'achieved_tflops_whole_path_padded': round(value * padded / 1e12, 2),
+            'cer_vs_reference': cer['cer_vs_reference'] if cer else None, 'cer': cer,
+            **extra,
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
             'labels_emitted_last_step': int(sum(len(r) for r in recs)),
         }

@@ -1,7 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the golden vectors made by the reference and
-against the CPU oracle.  Tolerances: fp32 mode 1e-3 abs on logits (north_star); bf16 mode: greedy
-labels identical on every frame whose reference top-2 margin exceeds 2x the measured logit deviation,
-and a bounded logit deviation."""
+against the CPU oracle.  Tolerances: fp32 mode 1e-3 abs on logits (north_star); bf16 mode on these RANDOM-weight
+fixtures (flat logits: most top-2 margins are a few bf16 roundings wide): a bounded logit deviation and greedy labels
+identical on every frame whose reference top-2 margin exceeds the CONSTANT BF16_MARGIN = 2 x the deviation bound.
+String identity / CER of the bf16 mode is asserted on the peaked "text" fixtures in tests/test_hip_bf16_path.py."""
 import json
 import os
 
@@ -14,6 +15,8 @@ from tests.hip_util import hip_tap, make_engine, oracle_taps, run_hip
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
+BF16_DEV = 0.35          # bf16 operands, fp32 accumulate + fp32 residual stream, logits of magnitude ~20 (decoder gain 8)
+BF16_MARGIN = 2 * BF16_DEV
 LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
 
 
@@ -65,7 +68,7 @@ def _check_case(case, name, dtype, n=None):
     if dtype == 'fp32':
         sel = margins > 2 * FP32_TOL
     else:
-        sel = margins > 2 * max(dev, 0.05)
+        sel = margins > BF16_MARGIN
     mism = int((labels[sel] != g['labels'][:n][sel]).sum())
     _log(f'{name}_{dtype}', {'max_abs_logit_dev': dev, 'frames': int(sel.size), 'frames_checked': int(sel.sum()), 'label_mismatch': mism,
                              'label_mismatch_all_frames': int((labels != g['labels'][:n]).sum())})
@@ -88,7 +91,7 @@ def test_fp32_cfg2_full_batch(case):
 def test_bf16_labels_identical_outside_margin(case, name):
     dev, mism, *_ = _check_case(case, name, 'bf16')
     assert mism == 0
-    assert dev <= 0.35      # bf16 operands, fp32 accumulate + fp32 residual stream (reference under CPU bf16 autocast: ~0.05 on logits of 1/8 this gain)
+    assert dev <= BF16_DEV      # (the reference itself under CPU bf16 autocast: ~0.05 on logits of 1/8 this gain)
 
 
 def test_u8_ingest_equals_f32_ingest(case):
@@ -164,7 +167,7 @@ def test_small_batch_form_of_the_chain_kernels(case):
     BITS as lines 0..3 of the full 32-line batch computed by the 96-row form (identical arithmetic per row)."""
     hp, state, image, lens, g = case('cfg2')
     dev, mism, eng, small, _ = _check_case(case, 'cfg2', 'bf16', n=4)
-    assert mism == 0 and dev <= 0.35
+    assert mism == 0 and dev <= BF16_DEV
     _, full, _ = run_hip(hp, state, image, lens, 'bf16')
     np.testing.assert_array_equal(small, full[:4])
 
