@@ -49,6 +49,7 @@ SYMBOLS = {
     'cocr_preproc_width': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'cocr_preproc_lines': (_I, [_P, _P, C.POINTER(C.c_int64), _I32P, _I32P, _I32P, _I, _I, _I, _I, _P, _I32P, _P]),
     'cocr_set_graph': (_I, [_P, _I]),
+    'cocr_set_chain_rows': (_I, [_P, _I]),
     'cocr_set_debug': (_I, [_P, _I]),
     'cocr_debug_tap': (_I, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     'cocr_profile': (_I, [_P, _I]),
@@ -60,7 +61,7 @@ _lib: Optional[C.CDLL] = None
 
 
 def lib_path() -> str:
-    return _build.LIB
+    return os.environ.get('COCR_LIB_PATH') or _build.LIB
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:
@@ -73,7 +74,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             return _lib
         import torch  # noqa: F401  (loads libamdhip64 of the torch wheel)
         path = lib_path()
-        if build_if_missing and not _build.up_to_date():
+        dev_lib = path != _build.LIB                  # COCR_LIB_PATH: an experiment build, loaded as it is
+        if build_if_missing and not dev_lib and not _build.up_to_date():
             try:
                 _build.build(verbose=False)
             except Exception as e:
@@ -94,7 +96,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         ver = (lib.cocr_version() or b'').decode()
-        if _build.built_hash() and f'src={_build.built_hash()}' not in ver and os.environ.get('COCR_ALLOW_STALE_LIB') != '1':
+        if not dev_lib and _build.built_hash() and f'src={_build.built_hash()}' not in ver and os.environ.get('COCR_ALLOW_STALE_LIB') != '1':
             raise RuntimeError(f'{path} reports "{ver}" but its build record says src={_build.built_hash()}: rebuild with '
                                '`python -m conformer_ocr_amd.build --force`')
         _lib = lib

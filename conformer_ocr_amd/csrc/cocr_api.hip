@@ -25,7 +25,8 @@
 #include "train.hip.h"
 #include "gemm.hip.h"
 #include "ffn.hip.h"
-#include "chain.hip.h"
+#include "rowchain_args.hip.h"
+#include "pack.hip.h"
 #include "frontend.hip.h"
 #include "norm.hip.h"
 #include "preproc.hip.h"
@@ -91,7 +92,7 @@ struct cocr_model {
     int dtype = -1;
     unsigned char *blob = nullptr;
     BlobPlan plan;
-    // fragment-major copies of the chain kernels' weight matrices (chain.hip.h), at the blob's offsets; derived from the blob,
+    // fragment-major copies of the row-chain kernels' weight matrices (rowchain.hip.h), at the blob's offsets; derived from the blob,
     // rebuilt before the next forward whenever the blob may have changed (finalize, import, cocr_weight_blob handed out)
     unsigned char *packed = nullptr;
     bf16_t *fpack = nullptr;     // fused frontend kernel (frontend.hip.h): conv.0 A-fragments, then the depthwise block-diagonal B-fragments
@@ -106,7 +107,6 @@ struct cocr_model {
     int vtN = -1, vtT = -1;    // shape the q/k/vt buffers were last zeroed for
     unsigned char *pre_buf = nullptr;      // line pre-processing: descriptors, tap tables, intermediates
     size_t pre_cap = 0;
-    void *dump = nullptr;      // 16 KiB sink for predicated-off stores of the chain kernels
     int32_t *d_lens = nullptr, *h_lens = nullptr, *d_lens_cur = nullptr;      // device / pinned-host rings of per-line lengths (upload_lens)
     int lens_slot = 0;
     int32_t *ctc_lab = nullptr;
@@ -131,12 +131,12 @@ struct cocr_model {
     struct GraphEntry { const void *lines; float *logits; int N, W, dtype; hipStream_t s; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs, graph_seen;
     bool debug = false;
-    unsigned long long *stamps = nullptr;   // COCR_CHAIN_STAMPS=1 (dev): host-visible cycle stamps of one chain launch, printed at destroy
+    unsigned long long *stamps = nullptr;   // COCR_CHAIN_STAMPS=1 (dev builds): host-visible cycle stamps of the frontend / attention / beam kernels, printed at destroy
     bool beam_ref = false;       // COCR_BEAM_REF=1: the exhaustive beam kernel (all beam x C candidates per frame) also for <= 256 classes
     bool no_front96 = false;     // COCR_NO_FRONT96=1: frontend conv stages as separate kernels (A/B)
     bool no_conv_mfma = false;   // COCR_NO_CONV_MFMA=1: the all-VALU fp32 frontend conv kernel also in bf16 mode (A/B)
     bool no_dw_fuse = false;     // COCR_NO_DW_FUSE=1: depthwise conv as its own launch (A/B)
-    bool chain48 = false;        // COCR_CHAIN48=1: the 48-row LDS-DMA chain kernels instead of the 96-row register-streamed ones (A/B)
+    int chain_rows = 0;          // rows per workgroup of the row-chain kernels (cocr_set_chain_rows / COCR_CHAIN_ROWS); 0 = by the number of rows
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
@@ -189,7 +189,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     m->ncls = hp->num_classes; m->H = hp->height; m->snum = snum;
     { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CHAIN"); m->no_chain = e && e[0] == '1'; }
-    { const char *e = getenv("COCR_CHAIN48"); m->chain48 = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_CHAIN_ROWS"); m->chain_rows = e ? atoi(e) : 0; }
     { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_FRONT96"); m->no_front96 = e && e[0] == '1'; }
@@ -259,9 +259,7 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->pre_buf) (void)hipFree(m->pre_buf);
     if (m->stamps) {
         (void)hipDeviceSynchronize();
-        fprintf(stderr, "chain stamps (cycles since first):");
-        for (int i = 1; i < 128 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[0]);
-        fprintf(stderr, "\nfrontend stamps:");
+        fprintf(stderr, "frontend stamps:");
         for (int i = 129; i < 192 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[128]);
         fprintf(stderr, "\nbeam phase cycles (setup, folds, candidates, selection, update):");
         for (int i = 240; i < 245 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i]);
@@ -619,7 +617,6 @@ extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
     const size_t M = (size_t)N * T, Tp = round_up(T, 32);
     int rc;
     const size_t zbytes = (size_t)N * T2 * m->feats[1] * m->C * es;
-    if ((rc = ws_alloc(m, &m->dump, 16384))) return rc;
     if ((rc = ws_alloc(m, &m->z_a, zbytes))) return rc;
     if ((rc = ws_alloc(m, &m->z_b, zbytes))) return rc;
     if ((rc = ws_alloc(m, (void **)&m->x, M * m->D * 4))) return rc;
@@ -884,10 +881,9 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     }
     char nm[64];
     if constexpr (sizeof(T) == 2) {
-        if (rowln && chain_supported(D, ff, dh) && !m->no_chain && !(m->debug && m->chain48)) {
-            // ---- row-local chains (chain.hip.h): 4 launches per block
-            const bool c96 = !m->chain48;
-            const unsigned char *CW = c96 ? m->packed : B;       // chain weights: fragment-major copies or the row-major blob
+        if (rowchain_supported(D, ff, dh) && !m->no_chain && !(m->debug && m->ksz != 31)) {      // (debug taps exist for the depthwise-fused chain shapes)
+            // ---- row-local chains (rowchain.hip.h): 3 launches per block (attention core, chain A, chain B)
+            const unsigned char *CW = m->packed;                 // chain weights: fragment-major copies
             auto CWT = [&](size_t off) { return (const bf16_t *)(CW + off); };
             // debug taps: the TAPS instantiation of the SAME kernels copies what never leaves the chip (or is overwritten inside the
             // launch) into tapbuf; everything else is read from the buffers the launches leave behind
@@ -911,14 +907,14 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 if ((r = tapb(l, "q", q, m->qkv_bytes / sizeof(T))) || (r = tapb(l, "k", k, m->qkv_bytes / sizeof(T))) || (r = tapb(l, "v", v, m->qkv_bytes / sizeof(T)))) return r;
                 return COCR_OK;
             };
-            auto launch = [&](const ChainArgs &a) { return c96 ? launch_chain96(s, a, taps) : launch_chain(s, a, ff); };
-            auto base = [&]() { ChainArgs a{}; a.dump = (float *)m->dump; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
+            auto launch = [&](const ChainArgs &a) { return D == 256 ? launch_rowchain_256(s, a, taps, m->chain_rows) : launch_rowchain_512(s, a, taps, m->chain_rows); };
+            auto base = [&]() { ChainArgs a{}; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
             auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
-                ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha; st.has_resid = 1;
+                ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha;
                 st.g1 = F32(g1); st.b1 = F32(b1); return st; };
             auto st_ffn = [&](const FfnW &fw, size_t g1, size_t b1, long g2, long b2) {
                 ChainStage st{}; st.kind = ST_FFN; st.W = CWT(fw.w1); st.W2 = CWT(fw.w2); st.bias = F32(fw.b1); st.bias2 = F32(fw.b2);
-                st.N = ff; st.alpha = ffr; st.has_resid = 1; st.g1 = F32(g1); st.b1 = F32(b1);
+                st.N = ff; st.alpha = ffr; st.g1 = F32(g1); st.b1 = F32(b1);      // (W2's fragment-major copy is pre-scaled by ffr: ensure_packed)
                 st.g2 = g2 >= 0 ? F32((size_t)g2) : nullptr; st.b2 = b2 >= 0 ? F32((size_t)b2) : nullptr; return st; };
             auto st_qkv = [&](const LayerW &lw) {
                 ChainStage st{}; st.kind = ST_QKV; st.W = CWT(lw.wqkv); st.bias = F32(lw.bqkv); st.N = 3 * D;
@@ -950,7 +946,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                     { ProfScope ps(m, s, FAM_CH_A); GEMM_TRY(launch(a)); }
                     if (taps && ((rc = tapx(l, "mhsa", tp[0])) || (rc = tapb(l, "glu", glu, (size_t)M * D)))) return rc;
                 }
-                const bool dw_fused = c96 && m->ksz == 31 && !m->no_dw_fuse;      // depthwise conv as the chain's prologue
+                const bool dw_fused = m->ksz == 31 && (!m->no_dw_fuse || taps);      // depthwise conv as the chain's prologue
                 if (!dw_fused) {
                     ProfScope ps(m, s, FAM_DW);
                     launch_dwconv<T>(s, glu, N, Tn, D, m->ksz, F32(w.dww), F32(w.dwb), dwo);
@@ -973,7 +969,6 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                         a.st[3] = st_qkv(nx);
                         a.nstages = 4;
                         a.st[1].tap_pre = tp[1]; a.st[1].tap_post = tp[2]; a.st[2].tap_pre = tp[3];
-                        if (l == 5) a.stamps = m->stamps;
                         { ProfScope ps(m, s, FAM_CH_B); GEMM_TRY(launch(a)); }
                         if (taps && ((rc = tap_common()) || (rc = tapx(l, "out", tp[2])) || (rc = tapx(l + 1, "ffn1", tp[3])) || (rc = tap_qkv(l + 1)))) return rc;
                     } else {
@@ -1054,7 +1049,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
 // (Re)builds the fragment-major weight copies the 96-row chain kernels read.  Runs on `s` ahead of the forward's launches
 // (stream order covers a blob import issued on the same stream), never inside a graph capture.
 static bool uses_chain96(const cocr_model *m) {
-    return m->dtype == COCR_BF16 && gemm_rowln_supported<bf16_t>(m->D) && chain_supported(m->D, m->ff, m->dh) && !m->no_chain && !m->chain48;
+    return m->dtype == COCR_BF16 && rowchain_supported(m->D, m->ff, m->dh) && !m->no_chain;
 }
 static bool uses_frontend96(const cocr_model *m) {
     return m->dtype == COCR_BF16 && m->snum == 2 && frontend96_supported(m->C, m->feats[0], m->feats[1], m->H) && !m->no_front96;
@@ -1063,13 +1058,14 @@ static int ensure_packed(cocr_model *m, hipStream_t s) {
     if ((!uses_chain96(m) && !uses_frontend96(m)) || !m->packed_stale) return COCR_OK;
     if (!m->packed) HIP_TRY(hipMalloc((void **)&m->packed, m->plan.total));
     const int D = m->D, ff = m->ff, C = m->C;
-    auto pack = [&](size_t off, int N, int K) {
+    auto pack = [&](size_t off, int N, int K, float scale = 1.0f) {
         hipLaunchKernelGGL(pack_frag_kernel, dim3(std::min(1024, ceil_div(N * K / 8, 256))), dim3(256), 0, s, (const bf16_t *)(m->blob + off),
-                           (bf16_t *)(m->packed + off), N, K);
+                           (bf16_t *)(m->packed + off), N, K, scale);
     };
+    const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;       // the FFN's residual factor rides on the packed copy of its second matrix (exact)
     if (uses_chain96(m))
         for (const LayerW &w : m->plan.layers) {
-            for (int i = 0; i < 2; ++i) { pack(w.ffn[i].w1, ff, D); pack(w.ffn[i].w2, D, ff); }
+            for (int i = 0; i < 2; ++i) { pack(w.ffn[i].w1, ff, D); pack(w.ffn[i].w2, D, ff, ffr); }
             pack(w.wqkv, 3 * D, D); pack(w.wo, D, D); pack(w.wpw1, 2 * D, D); pack(w.wpw2, D, D);
         }
     if (uses_frontend96(m)) {
@@ -1497,6 +1493,17 @@ extern "C" int cocr_dev_bench_gemm(int variant, int M, int N, int K, int iters, 
     *us_out = (double)ms * 1e3 / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(O); (void)hipFree(X); (void)hipFree(bias); (void)hipFree(gam);
+    return COCR_OK;
+}
+
+extern "C" int cocr_set_chain_rows(cocr_model *m, int rows) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    if (rows < 0 || rows > 96) return fail(COCR_EINVAL, "rows per workgroup must be in 0..96");
+    if (rows != m->chain_rows) {          // captured launch sequences use the old grid
+        for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear(); m->graph_seen.clear();
+    }
+    m->chain_rows = rows;
     return COCR_OK;
 }
 

@@ -2,7 +2,7 @@
 //     Conv2d(1,C,3,s2,p1) + ReLU  ->  depthwise Conv2d(C,C,3,s2,p1)  ->  pointwise Conv2d(C,C,1) + ReLU
 // (reference conformer/convolution.py:192-205).  Neither the (B,C,W/2,H/2) tensor Z1 nor the depthwise output Z2 is
 // ever written: a workgroup owns 4 output frames of one line = 4 x 24 = 96 rows of the (B*T*F, C) activation, builds
-// them as the 96 x 256 bf16 operand image of the chain kernels (chain.hip.h) and runs the pointwise conv on it with the
+// them as the 96 x 256 bf16 operand image of the chain kernels (rowchain.hip.h) and runs the pointwise conv on it with the
 // same register-streamed weight ring.  All three convolutions run on the matrix cores:
 //   * conv.0: (pixels x 9) x (9 x C), K padded to 16 as k = 4 dt + df -- a lane's 4 k-values are 4 consecutive image rows
 //     of one image column: two 4-byte LDS reads from the transposed bf16 line tile (no im2col buffer); channels on the MFMA
@@ -15,7 +15,7 @@
 // Z1 is held 64 channels at a time ([9 columns][50 rows][64 ch] bf16 tile), 4 passes.  Arithmetic: bf16 operands (pixels,
 // all weights, Z1, Z2), fp32 accumulation -- the fp32 mode keeps the VALU kernel + GEMM.
 #pragma once
-#include "chain.hip.h"
+#include "gemm.hip.h"
 #include "conv.hip.h"
 
 // ---- weight images built once per model (cocr_api: ensure_packed) -----------------------------------------------

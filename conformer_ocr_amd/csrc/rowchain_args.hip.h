@@ -1,0 +1,42 @@
+// Arguments of the row-chain kernels (rowchain.hip.h) and the entry points of their two translation units (rowchain_d256.hip,
+// rowchain_d512.hip: the template instantiations are compiled beside cocr_api.hip, in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hip.h"
+
+enum { ST_ROWLN = 0, ST_FFN = 1, ST_GLU = 2, ST_QKV = 3 };
+
+struct ChainStage {
+    int kind;
+    const bf16_t *W;       // fragment-major copies.  ROWLN / GLU / QKV: (N, D); FFN: W1 (FF, D)
+    const bf16_t *W2;      // FFN: alpha * W2 (D, FF)
+    const float *bias;     // ROWLN / GLU / QKV: (N); FFN: b1 (FF)
+    const float *bias2;    // FFN: b2 (D)
+    int N;                 // output columns (D / 2D / 3D) or FF
+    float alpha;           // FFN residual factor (already folded into W2; applied to b2 here)
+    const float *g1, *b1, *g2, *b2;    // LayerNorm(s) after the residual add (g2 != null: chained, x <- LN1)
+    int store_x, store_xn;             // write the fp32 stream / the normalised operand back to global after this stage
+    bf16_t *out;           // GLU: (M, D)
+    bf16_t *q, *k, *v;     // QKV
+    float *tap_pre, *tap_post;         // debug taps (TAPS instantiation only): (M, D) fp32 copies of the stream after this stage's residual
+                                       // add, and (chained LayerNorms) after the first LayerNorm; null = not wanted
+};
+
+struct ChainArgs {
+    const bf16_t *A0;      // first operand rows (M, D) (unused with the depthwise prologue)
+    float *x;              // fp32 residual stream (M, D): read at the start, written by the stages that have store_x
+    bf16_t *xn;            // normalised operand (M, D), written when a stage asks for it
+    int M, nstages;
+    const bf16_t *dw_in;   // depthwise-conv prologue: GLU output (M, D)
+    const float *dw_w, *dw_b;      // BatchNorm-folded depthwise taps [k][D] and bias [D]
+    bf16_t *tap_dw;        // debug tap (TAPS instantiation): (M, D) copy of the prologue's output, or null
+    int dh, dhp, heads, T_, Tp;       // attention layout of the QKV stage
+    ChainStage st[4];
+};
+
+static inline bool rowchain_supported(int D, int FF, int dh) { return (D == 256 || D == 512) && FF % 256 == 0 && FF >= 256 && FF <= 2048 && dh % 8 == 0 && D % dh == 0; }
+
+// `taps`: the debug instantiation; `rows_hint`: rows per workgroup (0 = pick by the number of rows, see rowchain_pick_mt)
+hipError_t launch_rowchain_256(hipStream_t s, const ChainArgs &a, bool taps, int rows_hint);
+hipError_t launch_rowchain_512(hipStream_t s, const ChainArgs &a, bool taps, int rows_hint);

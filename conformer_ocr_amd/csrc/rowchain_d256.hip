@@ -1,0 +1,4 @@
+// Translation unit of the row-chain kernels for encoder_dim 256 (rowchain.hip.h).
+#include "rowchain.hip.h"
+
+hipError_t launch_rowchain_256(hipStream_t s, const ChainArgs &a, bool taps, int rows_hint) { return launch_rowchain<256>(s, a, taps, rows_hint); }

@@ -118,6 +118,10 @@ class HipRecognizer:
         """hipGraph replay of repeated identical forwards (same input / output buffers): see include/cocr.h."""
         _lib.check(self.lib.cocr_set_graph(self._h, int(on)))
 
+    def set_chain_rows(self, rows: int) -> None:
+        """Rows per workgroup of the row-chain kernels (0 = automatic): see include/cocr.h."""
+        _lib.check(self.lib.cocr_set_chain_rows(self._h, int(rows)))
+
     def forward(self, lines: torch.Tensor, lens: Sequence[int], out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, np.ndarray]:
         """lines: (N,H,W) float32 or uint8 on this device, contiguous.  Returns (logits (N,T,ncls) f32 device, out_lens int32 host).
         `out`: optional preallocated logits buffer (keeps the output address fixed for graph replay)."""

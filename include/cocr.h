@@ -176,6 +176,13 @@ int cocr_preproc_lines(cocr_model *m, const uint8_t *pixels, const int64_t *offs
  * must then keep `lines` / `logits` at the same addresses (contents may change).  Off by default. */
 int cocr_set_graph(cocr_model *m, int on);
 
+/* Rows of the (N*T, D) activation one workgroup of the row-chain kernels owns (bf16 mode, encoder_dim 256 / 512).
+ * 0 (default): by the batch's row count -- the largest block (96 rows at D = 256, 64 at D = 512: every weight byte is
+ * streamed once per block, the cheapest form when several batches are in flight).  A caller with ONE batch in flight
+ * gets a shorter forward from smaller blocks (e.g. 48: twice the workgroups, 32 lines x 300 frames = 200 workgroups).
+ * Same results bit for bit (a row's arithmetic does not depend on the block it is in). */
+int cocr_set_chain_rows(cocr_model *m, int rows);
+
 /* Test taps: with debug on, cocr_forward keeps a float32 copy of every stage output
  * ("front.z2", "front.z3", "front.y", "l<i>.ffn1|mhsa|conv|ffn2|out", "l<i>.q|k|v|ctx|glu|dw").
  * cocr_debug_tap copies one to HOST memory; *n_elems receives its element count. */
