@@ -62,7 +62,7 @@ struct HostTensor {
 struct FfnW { size_t ln_g, ln_b, w1, b1, w2, b2; };
 struct LayerW {
     FfnW ffn[2];
-    size_t a_ln_g, a_ln_b, wqkv, bqkv, ub, vb, ptab, wo, bo;
+    size_t a_ln_g, a_ln_b, wqkv, bqkv, ub, vb, wpos, wo, bo;       // wpos: pos_proj weight, fp32 (D, D): the positional tables are DERIVED from it
     size_t c_ln_g, c_ln_b, wpw1, bpw1, dww, dwb, wpw2, bpw2;
     size_t f_ln_g, f_ln_b;
 };
@@ -97,6 +97,11 @@ struct cocr_model {
     unsigned char *packed = nullptr;
     bf16_t *fpack = nullptr;     // fused frontend kernel (frontend.hip.h): conv.0 A-fragments, then the depthwise block-diagonal B-fragments
     bool packed_stale = true;
+    // positional tables P_l = PE Wpos_l^T, [layer][9999][heads][dhp] in the compute dtype: derived from the blob's wpos matrices on this device
+    // (finalize, import, handed-out blob pointer) -- 61 of the former 104 MB of the cfg2 blob, which every rank can compute for itself
+    unsigned char *ptab = nullptr;
+    size_t ptab_stride = 0;
+    bool ptab_stale = true;
     // workspace
     int capN = 0, capW = 0;
     std::vector<void *> ws_allocs;
@@ -255,6 +260,7 @@ extern "C" void cocr_destroy(cocr_model *m) {
     clear_taps(m);
     if (m->blob) (void)hipFree(m->blob);
     if (m->packed) (void)hipFree(m->packed);
+    if (m->ptab) (void)hipFree(m->ptab);
     if (m->fpack) (void)hipFree(m->fpack);
     if (m->pre_buf) (void)hipFree(m->pre_buf);
     if (m->stamps) {
@@ -363,7 +369,7 @@ static BlobPlan make_plan(const cocr_model *m, int dtype) {
         w.a_ln_g = take(D * 4); w.a_ln_b = take(D * 4);
         w.wqkv = take((size_t)3 * D * D * es); w.bqkv = take((size_t)3 * D * 4);
         w.ub = take(D * 4); w.vb = take(D * 4);
-        w.ptab = take((size_t)COCR_POS_ROWS * m->heads * m->dhp * es);
+        w.wpos = take((size_t)D * D * 4);
         w.wo = take((size_t)D * D * es); w.bo = take(D * 4);
         w.c_ln_g = take(D * 4); w.c_ln_b = take(D * 4);
         w.wpw1 = take((size_t)2 * D * D * es); w.bpw1 = take((size_t)2 * D * 4);
@@ -411,13 +417,15 @@ static int expect_shape(const cocr_model *m, const std::string &name, std::initi
     return COCR_OK;
 }
 
-template <typename T> static int compute_pos_tables(cocr_model *m, const std::vector<const HostTensor *> &wpos);
+static int ensure_ptab(cocr_model *m, hipStream_t s);
 
 static int alloc_blob(cocr_model *m, int dtype) {
     if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");
     HIP_TRY(hipSetDevice(m->device));
     if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
     if (m->packed) { (void)hipFree(m->packed); m->packed = nullptr; }
+    if (m->ptab) { (void)hipFree(m->ptab); m->ptab = nullptr; }
+    m->ptab_stale = true;
     if (m->fpack) { (void)hipFree(m->fpack); m->fpack = nullptr; }
     if (m->tr_state) { (void)hipFree(m->tr_state); m->tr_state = nullptr; m->tr_step = 0; }      // optimizer state belongs to the old weights
     m->packed_stale = true;
@@ -441,7 +449,7 @@ extern "C" int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes)
     if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
     *device_ptr = m->blob;
     *bytes = m->plan.total;
-    m->packed_stale = true;          // the caller may write through the pointer: derived copies are rebuilt by the next forward
+    m->packed_stale = m->ptab_stale = true;          // the caller may write through the pointer: derived copies are rebuilt by the next forward
     return COCR_OK;
 }
 
@@ -461,7 +469,7 @@ extern "C" int cocr_blob_import(cocr_model *m, const void *src_device, size_t by
     if (bytes != m->plan.total) return fail(COCR_EINVAL, "blob is %zu bytes, buffer %zu", m->plan.total, bytes);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(m->blob, src_device, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    m->packed_stale = true;
+    m->packed_stale = m->ptab_stale = true;
     if (m->tr_state) { (void)hipFree(m->tr_state); m->tr_state = nullptr; m->tr_step = 0; }
     return COCR_OK;
 }
@@ -494,7 +502,6 @@ extern "C" int cocr_finalize(cocr_model *m, int dtype) {
         put_matrix(st + plan.wout, dtype, t->data.data(), D, F * C, nullptr, &colmap);
         GET("encoder.conv_subsample.out.0.bias", D); put_f32(st + plan.bout, t->data.data(), D);
     }
-    std::vector<const HostTensor *> wpos;
     for (int l = 0; l < m->L; ++l) {
         const LayerW &w = plan.layers[l];
         auto key = [&](const char *suffix) { snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.%s", l, suffix); return std::string(buf); };
@@ -518,7 +525,7 @@ extern "C" int cocr_finalize(cocr_model *m, int dtype) {
         }
         GET(key("1.module.attention.u_bias"), h, dh); put_f32(st + w.ub, t->data.data(), D);
         GET(key("1.module.attention.v_bias"), h, dh); put_f32(st + w.vb, t->data.data(), D);
-        GET(key("1.module.attention.pos_proj.linear.weight"), D, D); wpos.push_back(t);
+        GET(key("1.module.attention.pos_proj.linear.weight"), D, D); put_f32(st + w.wpos, t->data.data(), (size_t)D * D);
         GET(key("1.module.attention.out_proj.linear.weight"), D, D); put_matrix(st + w.wo, dtype, t->data.data(), D, D);
         GET(key("1.module.attention.out_proj.linear.bias"), D); put_f32(st + w.bo, t->data.data(), D);
         GET(key("2.module.sequential.0.weight"), D); put_f32(st + w.c_ln_g, t->data.data(), D);
@@ -557,15 +564,16 @@ extern "C" int cocr_finalize(cocr_model *m, int dtype) {
 #undef GET
     if ((rc = alloc_blob(m, dtype))) return rc;
     HIP_TRY(hipMemcpy(m->blob, st, plan.total, hipMemcpyHostToDevice));
-    rc = dtype == COCR_BF16 ? compute_pos_tables<bf16_t>(m, wpos) : compute_pos_tables<float>(m, wpos);
-    if (rc) return rc;
+    if ((rc = ensure_ptab(m, nullptr))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return COCR_OK;
 }
 
-// P_l = PE Wpos_l^T for all 9999 relative positions (embedding.py:35-56 table, attention.py:62,85
-// projection), computed once on the device in fp32 and stored head-padded in the compute dtype.
-template <typename T> static int compute_pos_tables(cocr_model *m, const std::vector<const HostTensor *> &wpos) {
+// P_l = PE Wpos_l^T for all 9999 relative positions (embedding.py:35-56 table, attention.py:62,85 projection), computed on the device in
+// fp32 from the blob's own wpos matrices and stored head-padded in the compute dtype.  Runs on `s` ahead of a forward's launches (stream
+// order covers a blob import issued on the same stream), never inside a graph capture; the same kernel on the same inputs on every rank,
+// so a rank that received the blob by broadcast holds bit-identical tables.
+template <typename T> static int compute_pos_tables(cocr_model *m, hipStream_t s) {
     const int D = m->D, R = COCR_POS_ROWS, maxlen = (R + 1) / 2;
     std::vector<float> pe((size_t)R * D);
     for (int r = 0; r < R; ++r) {
@@ -577,18 +585,27 @@ template <typename T> static int compute_pos_tables(cocr_model *m, const std::ve
             if (i + 1 < D) pe[(size_t)r * D + i + 1] = cosf(ang);
         }
     }
-    float *d_pe = nullptr, *d_w = nullptr;
+    float *d_pe = nullptr;
     HIP_TRY(hipMalloc((void **)&d_pe, pe.size() * 4));
-    HIP_TRY(hipMalloc((void **)&d_w, (size_t)D * D * 4));
-    HIP_TRY(hipMemcpy(d_pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(d_pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice, s));
     for (int l = 0; l < m->L; ++l) {
-        HIP_TRY(hipMemcpy(d_w, wpos[l]->data.data(), (size_t)D * D * 4, hipMemcpyHostToDevice));
-        EpiPosTable<T> epi{(T *)(m->blob + m->plan.layers[l].ptab), m->dh, m->dhp, m->heads};
-        HIP_TRY(launch_gemm<float>(0, d_pe, D, d_w, D, R, D, D, epi));
-        HIP_TRY(hipDeviceSynchronize());
+        EpiPosTable<T> epi{(T *)(m->ptab + (size_t)l * m->ptab_stride), m->dh, m->dhp, m->heads};
+        HIP_TRY(launch_gemm<float>(s, d_pe, D, (const float *)(m->blob + m->plan.layers[l].wpos), D, R, D, D, epi));
     }
+    HIP_TRY(hipStreamSynchronize(s));            // (pe is host memory of this call; one-time start-up work)
     HIP_TRY(hipFree(d_pe));
-    HIP_TRY(hipFree(d_w));
+    return COCR_OK;
+}
+static int ensure_ptab(cocr_model *m, hipStream_t s) {
+    if (!m->ptab_stale) return COCR_OK;
+    m->ptab_stride = (size_t)COCR_POS_ROWS * m->heads * m->dhp * esize(m->dtype);
+    if (!m->ptab) {
+        HIP_TRY(hipMalloc((void **)&m->ptab, m->ptab_stride * m->L));
+        HIP_TRY(hipMemsetAsync(m->ptab, 0, m->ptab_stride * m->L, s));          // padded head dims read as zero
+    }
+    int rc = m->dtype == COCR_BF16 ? compute_pos_tables<bf16_t>(m, s) : compute_pos_tables<float>(m, s);
+    if (rc) return rc;
+    m->ptab_stale = false;
     return COCR_OK;
 }
 
@@ -932,7 +949,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 {
                     ProfScope ps(m, s, FAM_ATTN);
                     dim3 grid(ceil_div(Tn, 64), N * heads);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
                     if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
                 }
@@ -997,7 +1014,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         {
             ProfScope ps(m, s, FAM_ATTN);
             dim3 grid(ceil_div(Tn, 64), N * heads);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, WT(w.ptab), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
             if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
         }
@@ -1095,7 +1112,7 @@ extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, in
     if (in_lens && out_lens)
         for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = ensure_packed(m, s))) return rc;
+    if ((rc = ensure_packed(m, s)) || (rc = ensure_ptab(m, s))) return rc;
     m->lastN = N;
     m->lastT = cocr_out_len(W, m->hp.subsampling_factor);
     auto run = [&]() -> int {

@@ -296,9 +296,11 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
         float s[MT], ss[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            // (explicit fused multiply-adds here and in `normalise`: every instantiation -- rows per workgroup, debug taps -- must round a row's
+            // statistics the same way, whatever the compiler's contraction choices are in that instantiation)
             f32x4 a = xs[i][0], b = xs[i][0] * xs[i][0];
 #pragma unroll
-            for (int c = 1; c < NJ; ++c) { a += xs[i][c]; b += xs[i][c] * xs[i][c]; }
+            for (int c = 1; c < NJ; ++c) { a += xs[i][c]; b = __builtin_elementwise_fma(xs[i][c], xs[i][c], b); }
             s[i] = (a[0] + a[1]) + (a[2] + a[3]);
             ss[i] = (b[0] + b[1]) + (b[2] + b[3]);
         }
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             }
             const float S = v[0] + v[2], SS = v[1] + v[3];
             mean[i] = S * inv_d;
-            rstd[i] = __builtin_amdgcn_rsqf(fmaxf(SS * inv_d - mean[i] * mean[i], 0.f) + 1e-5f);
+            const float ex2 = SS * inv_d;
+            rstd[i] = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean[i], mean[i], ex2), 0.f) + 1e-5f);
         }
     };
     // (x - mean) rstd gamma + beta for this lane's columns; which: 0 = (g1, b1), 1 = (g2, b2).  IN_PLACE: the stream itself is normalised
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const float r = rstd[i], mr = -mean[i] * r;
-                const f32x4 y = (xs[i][c] * (f32x4){r, r, r, r} + (f32x4){mr, mr, mr, mr}) * gv + bv;
+                const f32x4 y = __builtin_elementwise_fma(__builtin_elementwise_fma(xs[i][c], (f32x4){r, r, r, r}, (f32x4){mr, mr, mr, mr}), gv, bv);
                 if constexpr (in_place) {
                     xs[i][c] = y;
                 } else {

@@ -13,14 +13,19 @@ import torch
 import torch.distributed as dist
 
 
-def broadcast_weights(engine, src: int = 0, group=None) -> None:
+def broadcast_weights(engine, src: int = 0, group=None, source=None) -> None:
     """Rank `src` ran `finalize()`, the others `finalize_empty()`: ONE broadcast of the packed device blob
-    (RCCL over xGMI with the "nccl" backend), through a torch-owned staging buffer (`cocr_blob_export` / `_import`)."""
+    (RCCL over xGMI with the "nccl" backend), through a torch-owned staging buffer (`cocr_blob_export` / `_import`).
+    The blob holds the weights only (43 MB for the 12-block D=256 model); every rank derives the positional tables
+    (61 MB) from the broadcast pos_proj matrices on its own device at its next forward.
+    `source`: the engine that holds the weights on rank `src` if it is not `engine` itself (several engines per rank;
+    a single-rank rehearsal of the receive path) -- `engine` then imports the broadcast blob on EVERY rank."""
+    holder = engine if source is None else source
     buf = torch.empty(engine.blob_nbytes(), dtype=torch.uint8, device=engine.device)
     if dist.get_rank(group) == src:
-        engine.export_blob(buf)
+        holder.export_blob(buf)
     dist.broadcast(buf, src=src, group=group)
-    if dist.get_rank(group) != src:
+    if dist.get_rank(group) != src or holder is not engine:
         engine.import_blob(buf)
     torch.cuda.synchronize(engine.device)
 

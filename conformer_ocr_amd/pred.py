@@ -82,7 +82,7 @@ class PytorchRecognitionModel(nn.Module):
         """
         Inference version of a conformer_ocr RecognitionModel (pred.py:51-98).  Dropout
         probabilities are accepted and ignored (inference); unknown keyword arguments are ignored
-        like in the reference, except `compute_dtype` ('bf16' default, or 'fp32').
+        like in the reference, except `compute_dtype` ('bf16' default, or 'fp32') and `chain_rows`.
         """
         super().__init__()
         self.hparams_record = HParams(num_classes=num_classes, height=height, encoder_dim=encoder_dim,
@@ -105,6 +105,10 @@ class PytorchRecognitionModel(nn.Module):
         self.channels = 1
         self.width = 0
         self.compute_dtype = kwargs.get('compute_dtype', 'bf16')
+        # rows per workgroup of the row-chain kernels (include/cocr.h cocr_set_chain_rows).  This class is called one batch at a time
+        # (the reference's loop, cli/test.py:185-199): 48-row blocks give every CU a workgroup at 32 x 300 frames and the shortest
+        # forward; a caller that keeps several batches in flight on its own streams (bench.py) passes chain_rows=0.
+        self.chain_rows = int(kwargs.get('chain_rows', 48))
         self._engine: Optional[HipRecognizer] = None
         self._engine_sig = None
         self._sig_tensors = None
@@ -148,6 +152,7 @@ class PytorchRecognitionModel(nn.Module):
             eng = HipRecognizer(self.hparams_record, device, self.compute_dtype)
             eng.load_state({k: v for k, v in self.nn.state_dict().items()}, strict=True)
             eng.finalize()
+            eng.set_chain_rows(self.chain_rows)
             self._engine, self._engine_sig = eng, sig
         return self._engine
 

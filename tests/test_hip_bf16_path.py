@@ -126,6 +126,24 @@ def test_chain_kernel_stages_in_isolation_against_bf16_oracle(n, w):
     assert worst['chained logits vs bf16 oracle'] <= 0.05 and worst['chained logits vs fp32 oracle'] <= 0.15
 
 
+def test_rows_per_workgroup_forms_are_bit_identical():
+    """cocr_set_chain_rows: 32-, 48- and 96-row workgroups of the row-chain kernels compute every row with the same arithmetic in the same
+    order (explicit fused multiply-adds in the LayerNorm statistics: no instantiation-dependent contraction) -- bit-identical logits."""
+    hp = synth.hparams('cfg2', num_encoder_layers=2)
+    state = synth.make_state_dict(hp, seed=3, decoder_gain=1.0, style='text')
+    image, lens, _, _ = synth.make_text_lines(17, hp.height, 1200, seed=5)
+    x = torch.from_numpy(image[:, 0]).cuda()
+    eng = make_engine(hp, state, 'bf16')
+    out = {}
+    for rows in (0, 96, 48, 32):
+        eng.set_chain_rows(rows)
+        lg, _ = eng.forward(x, lens)
+        torch.cuda.synchronize()
+        out[rows] = lg.cpu().numpy().copy()
+    for rows in (96, 48, 32):
+        np.testing.assert_array_equal(out[0], out[rows])
+
+
 def _run_text_fixture(tc, dtype, env=None):
     """All batches of a text fixture through the C ABI; returns per-line (labels over the line's own frames, logits of lines 0/1)."""
     eng = make_engine(tc.hp, tc.state, dtype)
