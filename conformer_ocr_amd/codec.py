@@ -25,6 +25,7 @@ class PytorchCodec:
             self.l2c[tuple(v)] = k
         self.c_sorted = sorted(self.c2l.keys(), key=len, reverse=True)
         self.l_max_len = max((len(k) for k in self.l2c), default=0)
+        self._l2c1 = {k[0]: v for k, v in self.l2c.items()} if self.l_max_len == 1 else None      # 1:1 codecs: one dict lookup per label
 
     def __len__(self) -> int:
         return len(self.c2l)
@@ -56,6 +57,9 @@ class PytorchCodec:
     def decode(self, labels: Sequence[Tuple[int, int, int, float]]) -> List[Tuple[str, int, int, float]]:
         """(label, start, end, conf) records -> (char, start, end, conf) records by longest match of
         label subsequences against `l2c`; undecodable labels are skipped."""
+        if self._l2c1 is not None and not self.strict:
+            get = self._l2c1.get
+            return [(c, st, en, cf) for lab, st, en, cf in labels for code in (get(int(lab)),) if code is not None for c in code]
         start = [x[1] for x in labels]
         end = [x[2] for x in labels]
         con = [x[3] for x in labels]

@@ -107,6 +107,8 @@ struct cocr_model {
     std::vector<void *> ws_allocs;
     void *z_a = nullptr, *z_b = nullptr;
     float *x = nullptr;
+    void *g_lines = nullptr;           // staged graph replay (cocr_forward): library-owned copies of the caller's lines / logits
+    float *g_logits = nullptr;
     void *xn = nullptr, *hid = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *glu = nullptr, *dwo = nullptr;
     size_t qkv_bytes = 0;
     int vtN = -1, vtT = -1;    // shape the q/k/vt buffers were last zeroed for
@@ -646,6 +648,8 @@ extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
     if ((rc = ws_alloc(m, &m->ctx, M * m->D * es))) return rc;
     if ((rc = ws_alloc(m, &m->glu, M * m->D * es))) return rc;
     if ((rc = ws_alloc(m, &m->dwo, M * m->D * es))) return rc;
+    if ((rc = ws_alloc(m, &m->g_lines, (size_t)N * m->H * W * 4))) return rc;
+    if ((rc = ws_alloc(m, (void **)&m->g_logits, M * m->ncls * 4))) return rc;
     m->capN = N; m->capW = W;
     return COCR_OK;
 }
@@ -1115,42 +1119,72 @@ extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, in
     if ((rc = ensure_packed(m, s)) || (rc = ensure_ptab(m, s))) return rc;
     m->lastN = N;
     m->lastT = cocr_out_len(W, m->hp.subsampling_factor);
-    auto run = [&]() -> int {
+    auto run_on = [&](const void *in, float *out) -> int {
         if (m->dtype == COCR_BF16) {
-            if (line_dtype == COCR_F32) return forward_impl<bf16_t, float>(m, (const float *)lines, N, H, W, logits, s);
-            if (line_dtype == COCR_U8) return forward_impl<bf16_t, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
+            if (line_dtype == COCR_F32) return forward_impl<bf16_t, float>(m, (const float *)in, N, H, W, out, s);
+            if (line_dtype == COCR_U8) return forward_impl<bf16_t, uint8_t>(m, (const uint8_t *)in, N, H, W, out, s);
         } else {
-            if (line_dtype == COCR_F32) return forward_impl<float, float>(m, (const float *)lines, N, H, W, logits, s);
-            if (line_dtype == COCR_U8) return forward_impl<float, uint8_t>(m, (const uint8_t *)lines, N, H, W, logits, s);
+            if (line_dtype == COCR_F32) return forward_impl<float, float>(m, (const float *)in, N, H, W, out, s);
+            if (line_dtype == COCR_U8) return forward_impl<float, uint8_t>(m, (const uint8_t *)in, N, H, W, out, s);
         }
         return fail(COCR_EINVAL, "line dtype must be COCR_F32 or COCR_U8");
     };
+    auto run = [&]() -> int { return run_on(lines, logits); };
+    if (line_dtype != COCR_F32 && line_dtype != COCR_U8) return fail(COCR_EINVAL, "line dtype must be COCR_F32 or COCR_U8");
     if (!m->use_graph || m->debug || m->profile || s == nullptr) return run();
     // Launch-bound regime (~120 kernels of 10-40 us per forward): the second identical call captures the launch sequence
     // into a hipGraph, later identical calls replay it (one host call instead of ~120).
+    // Two kinds of captured sequences:
+    //   * keyed by the caller's buffers (lines, logits, N, W, dtype, stream): a loop that reuses its buffers replays with no extra copy;
+    //   * STAGED, keyed by (N, W, dtype, stream) only: a caller that hands over fresh buffers every call (a data loader's batches, torch's
+    //     allocator) gets one device-to-device copy of the lines into a library-owned staging buffer, the replay, and one copy of the
+    //     logits out (~20 MB at 32 x 96 x 1200 f32: a few microseconds) instead of ~40 host-side launches.
+    const int Tn = cocr_out_len(W, m->hp.subsampling_factor);
+    const bool shape_ready = m->vtN == N && m->vtT == Tn;      // the first call of a shape runs plain: one-time attribute / zeroing work
     auto same = [&](const cocr_model::GraphEntry &g) { return g.lines == lines && g.logits == logits && g.N == N && g.W == W && g.dtype == line_dtype && g.s == s; };
+    auto same_shape = [&](const cocr_model::GraphEntry &g) { return g.lines == nullptr && g.N == N && g.W == W && g.dtype == line_dtype && g.s == s; };
+    auto capture = [&](const void *in, float *out, hipGraphExec_t *exec) -> int {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int r = run_on(in, out);
+        hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
+        if (ce != hipSuccess) return fail(COCR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        HIP_TRY(hipGraphInstantiate(exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (m->graphs.size() >= 16) { (void)hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
+        return COCR_OK;
+    };
+    const size_t in_bytes = (size_t)N * H * W * (line_dtype == COCR_F32 ? 4 : 1), out_bytes = (size_t)N * Tn * m->ncls * 4;
+    auto staged_launch = [&](hipGraphExec_t exec) -> int {
+        HIP_TRY(hipMemcpyAsync(m->g_lines, lines, in_bytes, hipMemcpyDefault, s));
+        HIP_TRY(hipGraphLaunch(exec, s));
+        HIP_TRY(hipMemcpyAsync(logits, m->g_logits, out_bytes, hipMemcpyDeviceToDevice, s));
+        return COCR_OK;
+    };
     for (auto &g : m->graphs)
         if (same(g)) { HIP_TRY(hipGraphLaunch(g.exec, s)); return COCR_OK; }
-    bool seen = false;
-    for (auto &g : m->graph_seen) seen = seen || same(g);
-    if (!seen || m->vtN != N || m->vtT != cocr_out_len(W, m->hp.subsampling_factor)) {     // first call: plain (also does one-time attribute / zeroing work)
-        if (m->graph_seen.size() >= 32) m->graph_seen.erase(m->graph_seen.begin());     // bounded: a caller with fresh buffers per call never captures
-        m->graph_seen.push_back({lines, logits, N, W, line_dtype, s, nullptr});
+    bool seen = false, seen_shape = false;
+    for (auto &g : m->graph_seen) { seen = seen || same(g); seen_shape = seen_shape || same_shape(g); }
+    if (seen && shape_ready) {                       // the caller reuses its buffers: capture on them
+        hipGraphExec_t exec = nullptr;
+        if ((rc = capture(lines, logits, &exec))) return rc;
+        m->graphs.push_back({lines, logits, N, W, line_dtype, s, exec});
+        HIP_TRY(hipGraphLaunch(exec, s));
+        return COCR_OK;
+    }
+    if (m->graph_seen.size() >= 32) m->graph_seen.erase(m->graph_seen.begin());
+    m->graph_seen.push_back({lines, logits, N, W, line_dtype, s, nullptr});
+    for (auto &g : m->graphs)
+        if (same_shape(g)) return staged_launch(g.exec);
+    if (!seen_shape || !shape_ready) {               // first call of this shape: plain, on the caller's buffers
+        m->graph_seen.push_back({nullptr, nullptr, N, W, line_dtype, s, nullptr});
         return run();
     }
-    hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = run();
-    hipError_t ce = hipStreamEndCapture(s, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess) return fail(COCR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-    hipGraphExec_t exec = nullptr;
-    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    if (m->graphs.size() >= 16) { (void)hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
-    m->graphs.push_back({lines, logits, N, W, line_dtype, s, exec});
-    HIP_TRY(hipGraphLaunch(exec, s));
-    return COCR_OK;
+    hipGraphExec_t exec = nullptr;                   // second call of the shape with other buffers: capture the staged sequence
+    if ((rc = capture(m->g_lines, m->g_logits, &exec))) return rc;
+    m->graphs.push_back({nullptr, nullptr, N, W, line_dtype, s, exec});
+    return staged_launch(exec);
 }
 
 // ------------------------------------------------------------------------------------ CTC

@@ -153,6 +153,7 @@ class PytorchRecognitionModel(nn.Module):
             eng.load_state({k: v for k, v in self.nn.state_dict().items()}, strict=True)
             eng.finalize()
             eng.set_chain_rows(self.chain_rows)
+            eng.set_graph(True)        # hipGraph replay of the launch sequence, staged for the fresh tensors every call brings
             self._engine, self._engine_sig = eng, sig
         return self._engine
 

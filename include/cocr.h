@@ -171,9 +171,11 @@ int32_t cocr_preproc_width(int32_t h, int32_t w, int32_t out_h, int32_t pad);
 int cocr_preproc_lines(cocr_model *m, const uint8_t *pixels, const int64_t *offsets, const int32_t *heights, const int32_t *widths,
                        const int32_t *channels, int N, int out_h, int pad, int out_w, uint8_t *out, int32_t *out_widths, void *stream);
 
-/* Launch-overhead control: with graph replay on, the second cocr_forward call with identical (lines, logits, N, W,
- * dtype, stream) captures its ~120 kernel launches into a hipGraph and later identical calls replay it.  The caller
- * must then keep `lines` / `logits` at the same addresses (contents may change).  Off by default. */
+/* Launch-overhead control: with graph replay on, cocr_forward captures its ~40 kernel launches into a hipGraph and
+ * replays it.  A caller that reuses (lines, logits, N, W, dtype, stream) gets a graph on its own buffers (second
+ * identical call captures, later ones replay; contents may change, addresses not).  A caller with fresh buffers per
+ * call gets a graph keyed by (N, W, dtype, stream) on library-owned staging buffers: one device-to-device copy of the
+ * lines in and of the logits out per call.  Off by default. */
 int cocr_set_graph(cocr_model *m, int on);
 
 /* Rows of the (N*T, D) activation one workgroup of the row-chain kernels owns (bf16 mode, encoder_dim 256 / 512).
