@@ -198,6 +198,7 @@ def main():
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the streams1 / predict_string / ingest legs (profiling runs)')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a captured hipGraph')
+    ap.add_argument('--stagger-us', type=float, default=0.0, help='host-side offset between the first batches of a timed run (they would otherwise start in lockstep: all frontends, then all attention kernels, ... at the same time)')
     ap.add_argument('--streams', type=int, default=4, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL at communicator creation) go to stderr
@@ -286,6 +287,10 @@ def main():
             with torch.cuda.stream(streams[k]):
                 logits, out_lens = e.forward(batches[b]['x'], batches[b]['lens'], out=outs[k][b])
                 pending.append((e, e.ctc_greedy_async(logits, out_lens), b))
+            if i < nstreams - 1 and args.stagger_us > 0:
+                t_end = time.perf_counter() + args.stagger_us * 1e-6
+                while time.perf_counter() < t_end:
+                    pass
             if len(pending) >= nstreams:
                 pe, h, pb = pending.pop(0)
                 recs = pe.collect(h)

@@ -740,15 +740,18 @@ extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, d
     } while (0)
 
 template <typename T, int DHP>
-static hipError_t launch_attention(hipStream_t s, dim3 grid, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
+static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
                                    const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, unsigned long long *stamps = nullptr) {
     const size_t lds = attention_lds_bytes<T, DHP>();
     auto kern = relpos_attention_kernel<T, DHP>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
     if (e != hipSuccess) return e;
     // log2(e) rides on the 1/sqrt(d_head) factor folded into the query operands: the kernel's scores are in log2 units and its
-    // softmax uses v_exp_f32 (2^x) directly -- one multiply per score less
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh, scale * 1.44269504088896340736f, stamps);
+    // softmax uses v_exp_f32 (2^x) directly -- one multiply per score less.
+    // (80-query tiles -- 5 waves, 512 workgroups = one round of 2 per CU at cfg2 instead of 1280 in two rounds -- measured SLOWER:
+    // 19.4 us against 16.3 us per launch)
+    hipLaunchKernelGGL(kern, dim3(ceil_div(Tn, 64), N * heads), dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh,
+                       scale * 1.44269504088896340736f, stamps);
     return hipGetLastError();
 }
 
@@ -952,8 +955,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 const LayerW &w = P.layers[l];
                 {
                     ProfScope ps(m, s, FAM_ATTN);
-                    dim3 grid(ceil_div(Tn, 64), N * heads);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
                     if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
                 }
@@ -1017,8 +1019,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_ATTN);
-            dim3 grid(ceil_div(Tn, 64), N * heads);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, grid, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
             if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
         }
