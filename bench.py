@@ -85,28 +85,37 @@ def kernel_table(hp, n, w, dtype):
     }
 
 
-def cus_occupied(family, rows):
+def chain_block_rows(hp, rows):
+    """Rows per workgroup of the row-chain kernels in the throughput form (rowchain.hip.h rowchain_pick_mt)."""
+    big = 96 if hp.encoder_dim == 256 else 64
+    return big if rows >= big * 50 else 32
+
+
+def cus_occupied(family, hp, rows):
     """CUs a launch of `family` can occupy (MI355X: 256): the row-block chain kernels run one workgroup per CU."""
-    if family.startswith('chain_') and rows >= 4800:
-        return min(256, -(-rows // 96))
+    if family.startswith('chain_'):
+        return min(256, -(-rows // chain_block_rows(hp, rows)))
     return 256
 
 
-PROFILE_KERNEL_NAMES = {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu',
-                        'frontend_conv12': 'frontend_conv12', 'frontend_fused': 'frontend96_kernel',
-                        'chain_pw2_ffn_ffn_qkv': 'chain96_kernel<6, 31, 0, 1, 1, 3', 'chain_attn_out_glu': 'chain96_kernel<6, 0, 0, 2, -1, -1',
-                        'chain_ffn_qkv': 'chain96_kernel<6, 0, 1, 3, -1, -1', 'chain_pw2_ffn': 'chain96_kernel<6, 31, 0, 1, -1, -1'}
+def profile_kernel_name(family, hp, rows):
+    """Substring of the kernel's name in the rocprofv3 summaries."""
+    chain = {'chain_pw2_ffn_ffn_qkv': '31, 0, 1, 1, 3', 'chain_attn_out_glu': '0, 0, 2, -1, -1', 'chain_ffn_qkv': '0, 1, 3, -1, -1', 'chain_pw2_ffn': '31, 0, 1, -1, -1'}
+    if family in chain:
+        return f'rowchain_kernel<{hp.encoder_dim}, {chain_block_rows(hp, rows) // 16}, {chain[family]}'
+    return {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12',
+            'frontend_fused': 'frontend96_kernel'}.get(family)
 
 
-def pmc_traffic(family, live_avg_ms):
+def pmc_traffic(family, live_avg_ms, hp, rows, tag):
     """HBM bytes per launch of a kernel family from the NEWEST committed rocprofv3 PMC summary (PMC counters cannot be read from
     inside the process: they come from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this bench command, condensed
     by tools/summarize_rocprof.py).  Returned with the file it came from and a staleness flag: the kernel's average duration in
     the kernel-trace summary of the same round against the duration measured live in this run."""
     import csv
     import glob
-    name = PROFILE_KERNEL_NAMES.get(family)
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.csv')))
+    name = profile_kernel_name(family, hp, rows)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', f'*{tag}_pmc_traffic.csv')) if ('_cfg4' in os.path.basename(f)) == bool(tag))
     if name is None or not files:
         return None, None
     f = files[-1]
@@ -457,13 +466,13 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]['share'])
         d = kernels[dom]
         rows = batches[pb]['n'] * eng.out_len(batches[pb]['w'])
-        traffic, tinfo = pmc_traffic(dom, d['avg_ms'])
+        traffic, tinfo = pmc_traffic(dom, d['avg_ms'], hp, rows, '_cfg4' if args.config == 'cfg4' else '')
         roof = {'kernel': dom, 'bound': 'hbm' if d['bound'] == 'hbm' else 'mfma', 'achieved': d['achieved'], 'peak': d['peak'],
                 'unit': d['unit'], 'frac': d['frac'], 'traffic': traffic, 'traffic_profile': tinfo, 'avg_ms': d['avg_ms'], 'share_of_step': d['share'],
                 'algorithmic_per_launch': table[dom][1], 'event_pair_overhead_ms': round(ovh, 5),
                 'profiled_batch': {'lines': batches[pb]['n'], 'width': batches[pb]['w']},
                 # the row-block chain kernels launch ceil(rows / 96) workgroups of one per CU: `frac` prices them against the WHOLE chip
-                'cus_occupied': cus_occupied(dom, rows), 'frac_of_occupied_cus': round(d['frac'] * 256.0 / cus_occupied(dom, rows), 5),
+                'cus_occupied': cus_occupied(dom, hp, rows), 'frac_of_occupied_cus': round(d['frac'] * 256.0 / cus_occupied(dom, hp, rows), 5),
                 'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command, 2*FETCH+WRITE bytes per launch '
                                   '(newest profiles/*_pmc_traffic.csv; `traffic_profile.stale` compares that round\'s kernel duration with this run\'s)'}
 

@@ -571,7 +571,7 @@ template <int D> static inline int rowchain_pick_mt(int M, int rows_hint) {
     constexpr int MAXMT = D == 256 ? 6 : 4;
     if (rows_hint > 0) {
         const int mt = std::min(MAXMT, std::max(2, rows_hint / 16));
-        return (D == 256 && (mt == 4 || mt == 5)) ? 3 : (D == 512 && mt == 3) ? 2 : mt;      // instantiated: 6, 3, 2 (D = 256); 4, 2 (D = 512)
+        return (D == 256 && (mt == 4 || mt == 5)) ? 3 : (D == 512 && mt == 3) ? 4 : mt;      // instantiated: 6, 3, 2 (D = 256); 4, 2 (D = 512)
     }
     if (M >= 16 * MAXMT * 50) return MAXMT;
     return 2;
