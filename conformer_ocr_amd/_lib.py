@@ -41,6 +41,7 @@ SYMBOLS = {
     'cocr_reserve': (_I, [_P, _I, _I]),
     'cocr_forward': (_I, [_P, _P, _I, _I, _I, _I, _I32P, _P, _I32P, _P]),
     'cocr_ctc_greedy': (_I, [_P, _P, _I, _I, _I, _I32P, _P, _P, _P, _P, _P, _I, _P]),
+    'cocr_forget_argmax': (_I, [_P]),
     'cocr_ctc_beam': (_I, [_P, _P, _I, _I, _I, _I32P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'cocr_ctc_loss': (_I, [_P, _P, _I, _I, _I, _I32P, _I32P, _I32P, _P, _P, _P]),
     'cocr_decoder_backward': (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),

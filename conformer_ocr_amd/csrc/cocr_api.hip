@@ -117,6 +117,9 @@ struct cocr_model {
     int32_t *d_lens = nullptr, *h_lens = nullptr, *d_lens_cur = nullptr;      // device / pinned-host rings of per-line lengths (upload_lens)
     int lens_slot = 0;
     int32_t *ctc_lab = nullptr;
+    const float *amax_logits = nullptr;     // the logits buffer whose per-frame argmax / maximum the last forward left in ctc_lab / ctc_val (decoder epilogue)
+    int amax_rows = 0;
+    bool amax_ok = false;                   // the forward's launch sequence (plain or captured) ends with the argmax epilogue
     float *ctc_val = nullptr;
     size_t ctc_cap = 0;
     int32_t *beam_bp = nullptr;
@@ -756,6 +759,7 @@ static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k,
 }
 
 static bool uses_frontend96(const cocr_model *m);
+static int ensure_ctc_scratch(cocr_model *m, size_t rows);
 
 template <typename T, typename TIn>
 static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, float *logits, hipStream_t s) {
@@ -904,6 +908,24 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         m->vtN = N; m->vtT = Tn;
     }
     char nm[64];
+    // decoder nn.Linear (pred.py:90,121): logits fp32.  Up to 128 classes the product's epilogue also leaves the greedy decoder's per-frame
+    // argmax / maximum (ctc_lab / ctc_val): cocr_ctc_greedy on these logits then only merges runs.
+    auto decoder = [&](const T *xin) -> int {
+        ProfScope ps(m, s, FAM_DEC);
+        constexpr int BK = 128 / (int)sizeof(T);
+        if (m->ncls <= 128 && D % BK == 0 && (rc = ensure_ctc_scratch(m, (size_t)M)) == COCR_OK) {
+            EpiLogitsArgmax e{logits, m->ncls, F32(P.bdec), m->ncls, m->ctc_lab, m->ctc_val};
+            GemmArgs<T> a{xin, D, WT(P.wdec), D, M, m->ncls, D, 0};
+            GEMM_TRY((launch_ring_cfg<T, 64, 128, 3, EpiLogitsArgmax>(s, a, e)));
+            m->amax_ok = true; m->amax_rows = M;
+            return COCR_OK;
+        }
+        if (rc) return rc;
+        EpiStoreF32 e{logits, m->ncls, F32(P.bdec), m->ncls};
+        GEMM_TRY(launch_gemm<T>(s, xin, D, WT(P.wdec), D, M, m->ncls, D, e));
+        m->amax_ok = false;
+        return COCR_OK;
+    };
     if constexpr (sizeof(T) == 2) {
         if (rowchain_supported(D, ff, dh) && !m->no_chain && !(m->debug && m->ksz != 31)) {      // (debug taps exist for the depthwise-fused chain shapes)
             // ---- row-local chains (rowchain.hip.h): 3 launches per block (attention core, chain A, chain B)
@@ -1004,10 +1026,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                     }
                 }
             }
-            ProfScope ps(m, s, FAM_DEC);
-            EpiStoreF32 e{logits, m->ncls, F32(P.bdec), m->ncls};
-            GEMM_TRY(launch_gemm<T>(s, xn, D, WT(P.wdec), D, M, m->ncls, D, e));
-            return COCR_OK;
+            return decoder(xn);
         }
     }
     for (int l = 0; l < m->L; ++l) {
@@ -1060,12 +1079,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             if ((rc = ffn(w.ffn[1], w.f_ln_g, w.f_ln_b, -1, -1))) return rc;
         }
     }
-    {   // decoder nn.Linear (pred.py:90,121): logits fp32
-        ProfScope ps(m, s, FAM_DEC);
-        EpiStoreF32 e{logits, m->ncls, F32(P.bdec), m->ncls};
-        GEMM_TRY(launch_gemm<T>(s, xn, D, WT(P.wdec), D, M, m->ncls, D, e));
-    }
-    return COCR_OK;
+    return decoder(xn);
 }
 
 // (Re)builds the fragment-major weight copies the 96-row chain kernels read.  Runs on `s` ahead of the forward's launches
@@ -1104,8 +1118,22 @@ static int ensure_packed(cocr_model *m, hipStream_t s) {
     return COCR_OK;
 }
 
+static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W, const int32_t *in_lens,
+                         float *logits, int32_t *out_lens, void *stream);
 extern "C" int cocr_forward(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W, const int32_t *in_lens,
                             float *logits, int32_t *out_lens, void *stream) {
+    if (m) m->amax_logits = nullptr;
+    const int rc = forward_entry(m, lines, line_dtype, N, H, W, in_lens, logits, out_lens, stream);
+    if (rc == COCR_OK && m->amax_ok) m->amax_logits = logits;      // (plain run, replay or staged replay: the sequence ended with the argmax epilogue)
+    return rc;
+}
+extern "C" int cocr_forget_argmax(cocr_model *m) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    m->amax_logits = nullptr;
+    return COCR_OK;
+}
+static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W, const int32_t *in_lens,
+                         float *logits, int32_t *out_lens, void *stream) {
     if (!m || !lines || !logits) return fail(COCR_EINVAL, "null argument");
     if (m->dtype < 0 || !m->blob) return fail(COCR_ESTATE, "model not finalized");
     if (H != m->H) return fail(COCR_EINVAL, "line height %d does not match the model's height %d", H, m->H);
@@ -1212,6 +1240,21 @@ static int upload_lens(cocr_model *m, const int32_t *lens, int N, hipStream_t s)
     return COCR_OK;
 }
 
+static int ensure_ctc_scratch(cocr_model *m, size_t rows) {
+    if (rows > m->ctc_cap) {
+        HIP_TRY(hipDeviceSynchronize());                      // (captured launches that point at the old scratch are dropped with it)
+        for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear(); m->graph_seen.clear();
+        if (m->ctc_lab) (void)hipFree(m->ctc_lab);
+        if (m->ctc_val) (void)hipFree(m->ctc_val);
+        HIP_TRY(hipMalloc((void **)&m->ctc_lab, rows * 4));
+        HIP_TRY(hipMalloc((void **)&m->ctc_val, rows * 4));
+        m->ctc_cap = rows;
+        m->amax_logits = nullptr;
+    }
+    return COCR_OK;
+}
+
 extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T, int ncls, const int32_t *out_lens, int32_t *labels,
                                int32_t *starts, int32_t *ends, float *conf, int32_t *counts, int max_per_line, void *stream) {
     if (!m || !logits || !out_lens || !labels || !starts || !ends || !conf || !counts) return fail(COCR_EINVAL, "null argument");
@@ -1221,16 +1264,14 @@ extern "C" int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T,
     hipStream_t s = (hipStream_t)stream;
     int rc = upload_lens(m, out_lens, N, s);
     if (rc) return rc;
-    if ((size_t)N * T > m->ctc_cap) {
-        if (m->ctc_lab) (void)hipFree(m->ctc_lab);
-        if (m->ctc_val) (void)hipFree(m->ctc_val);
-        HIP_TRY(hipMalloc((void **)&m->ctc_lab, (size_t)N * T * 4));
-        HIP_TRY(hipMalloc((void **)&m->ctc_val, (size_t)N * T * 4));
-        m->ctc_cap = (size_t)N * T;
-    }
+    const bool have_argmax = logits == m->amax_logits && N * T == m->amax_rows && ncls == m->ncls;      // the decoder's epilogue computed it for these logits
+    if (!have_argmax && (rc = ensure_ctc_scratch(m, (size_t)N * T))) return rc;
     ProfScope ps(m, s, FAM_GREEDY);
-    hipLaunchKernelGGL(ctc_argmax_kernel, dim3(ceil_div(N * T, 4)), dim3(256), 0, s, logits, T, ncls, N * T, m->d_lens_cur, m->ctc_lab, m->ctc_val);
-    LAUNCH_CHECK();
+    if (!have_argmax) {
+        m->amax_logits = nullptr;                             // the scratch no longer belongs to the last forward's logits
+        hipLaunchKernelGGL(ctc_argmax_kernel, dim3(ceil_div(N * T, 4)), dim3(256), 0, s, logits, T, ncls, N * T, m->d_lens_cur, m->ctc_lab, m->ctc_val);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(64), (size_t)T * 8, s, T, m->d_lens_cur, m->ctc_lab, m->ctc_val, labels, starts, ends, conf, counts,
                        max_per_line);
     LAUNCH_CHECK();

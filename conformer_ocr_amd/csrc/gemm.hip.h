@@ -89,6 +89,54 @@ struct EpiStoreF32 {
     }
 };
 
+// Decoder logits + the greedy decoder's first half (kraken greedy_decoder: argmax over classes per frame, first index on ties -- the call
+// sites pred.py:143,162,177): out[m, :] = acc + bias as fp32, flab[m] = argmax, fval[m] = max.  Row-complete (BN >= N <= 128): a 16-lane
+// group takes one staged row, lane c of it the float4 chunks c and c + 16 (columns ascending inside a lane: strict > keeps the lowest
+// index), then four DPP steps inside the 16-lane row on (value, index) pairs, equal values resolved towards the lower index.
+struct EpiLogitsArgmax {
+    typedef float stage_t;
+    static constexpr bool GLU = false;
+    static constexpr bool ROWWISE = true;
+    float *out; int ldo; const float *bias; int N;
+    int32_t *flab; float *fval;
+    __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = v[i] + (n + i < N ? bias[n + i] : 0.f);
+    }
+    template <int CTRL> static __device__ __forceinline__ void step(float &v, int &i) {
+        const float ov = dpp_f32<CTRL, 0xF>(v, v);
+        const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false);
+        const bool take = ov > v || (ov == v && oi < i);
+        v = take ? ov : v;
+        i = take ? oi : i;
+    }
+    __device__ __forceinline__ void rows4(int m0, int M, const float *staged, int rs_floats, int lane) const {
+        const int rl = lane >> 4, cl = lane & 15, m = m0 + rl;
+        const float *row = staged + rl * rs_floats;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 4 * (cl + 16 * h);
+            if (c < N) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+                if (m < M) {
+                    if (c + 3 < N && (ldo & 3) == 0) *reinterpret_cast<f32x4 *>(out + (size_t)m * ldo + c) = v;
+                    else for (int i = 0; i < 4 && c + i < N; ++i) out[(size_t)m * ldo + c + i] = v[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c + i < N && (v[i] > best || bi == 0x7fffffff)) { best = v[i]; bi = c + i; }
+            }
+        }
+        step<0xB1>(best, bi);          // quad_perm(1,0,3,2)
+        step<0x4E>(best, bi);          // quad_perm(2,3,0,1)
+        step<0x141>(best, bi);         // row_half_mirror
+        step<0x140>(best, bi);         // row_mirror
+        if (cl == 0 && m < M) { flab[m] = bi; fval[m] = best; }
+    }
+};
+
 // x[m, n] += alpha * (acc + bias[n])  -- ResidualConnectionModule, modules.py:32 (input_factor 1)
 struct EpiResidual {
     typedef float stage_t;

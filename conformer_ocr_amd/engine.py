@@ -150,6 +150,7 @@ class HipRecognizer:
             _lib.check(self.lib.cocr_forward(self._h, C.c_void_p(lines.data_ptr()), ldt, N, H, W,
                                              in_lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(logits.data_ptr()),
                                              out_lens.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(self.device)))
+        self._fresh_logits = (logits.data_ptr(), logits._version)      # the decoder epilogue's per-frame argmax belongs to these values
         return logits, out_lens
 
     def _decode_async(self, fn, logits: torch.Tensor, out_lens, extra=()):
@@ -160,6 +161,8 @@ class HipRecognizer:
         logits = logits.contiguous()
         N, T, ncls = logits.shape
         lens = np.ascontiguousarray(np.asarray(out_lens, dtype=np.int32).reshape(-1))
+        if getattr(self, '_fresh_logits', None) != (logits.data_ptr(), logits._version):
+            _lib.check(self.lib.cocr_forget_argmax(self._h))          # other logits, or edited in place since the forward: decode from the values
         with torch.cuda.device(self.device):
             # The decode kernels write their (sparse) label records STRAIGHT into pinned host memory (device-visible): no
             # device->host copy is enqueued.  A third hipMemcpyAsync D2H in flight (three batches on three streams, each queued

@@ -114,10 +114,14 @@ int cocr_forward(cocr_model *m, const void *lines, int line_dtype, int N, int H,
  * logits DEVICE float32 (N,T,ncls); out_lens HOST int32 (N).  Outputs DEVICE, caller-owned:
  * labels/starts/ends int32 (N,max_per_line), conf float32 (N,max_per_line) = max over the run of the
  * label's logit, counts int32 (N).  A line emits at most ceil(len/1) runs; max_per_line >= T is safe;
- * excess runs are counted but not stored. */
+ * excess runs are counted but not stored.
+ * When `logits` is the buffer the model's LAST cocr_forward wrote (same pointer, same N*T; models of up to 128
+ * classes), the per-frame argmax was already taken in the decoder product's epilogue and only the run merge is
+ * launched.  A caller that edits those logits in place before decoding calls cocr_forget_argmax first. */
 int cocr_ctc_greedy(cocr_model *m, const float *logits, int N, int T, int ncls, const int32_t *out_lens,
                     int32_t *labels, int32_t *starts, int32_t *ends, float *conf, int32_t *counts,
                     int max_per_line, void *stream);
+int cocr_forget_argmax(cocr_model *m);
 
 /* CTC prefix beam search (kraken.lib.ctc_decoder.beam_decoder's algorithm on log-softmax(logits);
  * semantics fixed in oracle/ctc_ref.py::beam_decoder).  Same buffers as cocr_ctc_greedy; conf is a

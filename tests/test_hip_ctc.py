@@ -59,3 +59,36 @@ def test_callable_decoder_object():
     from conformer_ocr_amd.ctc_decoder import greedy_decoder
     m = np.random.default_rng(0).normal(size=(11, 40)).astype(np.float32)
     assert [x[:3] for x in greedy_decoder(m)] == [x[:3] for x in ref_greedy(m)]
+
+
+def test_argmax_in_the_decoder_epilogue_equals_the_argmax_kernel():
+    """Up to 128 classes the decoder product's epilogue leaves the per-frame argmax / maximum of the logits it writes; cocr_ctc_greedy on
+    those logits only merges runs.  Same records as the stand-alone argmax kernel (cocr_forget_argmax), including exact ties (first
+    index) and after an in-place edit of the logits (the Python wrapper notices the tensor's version and decodes from the values)."""
+    import torch
+    from conformer_ocr_amd import synth
+    from tests.hip_util import make_engine
+    hp = synth.hparams('cfg2', num_encoder_layers=1)
+    state = synth.make_state_dict(hp, seed=21, decoder_gain=8.0)
+    image, lens = synth.make_lines(5, hp.height, 333, seed=4, widths=[333, 100, 250, 17, 300])
+    x = torch.from_numpy(image[:, 0]).cuda()
+    for dtype in ('bf16', 'fp32'):
+        for ties in (False, True):
+            st = dict(state)
+            if ties:                                             # every frame: classes 5 and 9 tie for the maximum, then 0 and 3
+                st['decoder.weight'] = np.zeros_like(state['decoder.weight'])
+                b = np.full(hp.num_classes, -1.0, np.float32)
+                b[[5, 9]] = 2.0
+                st['decoder.bias'] = b
+            eng = make_engine(hp, st, dtype)
+            lg, ol = eng.forward(x, lens)
+            fused = eng.ctc_greedy(lg, ol)
+            eng.lib.cocr_forget_argmax(eng._h)
+            plain = eng.ctc_greedy(lg, ol)
+            assert fused == plain
+            if ties:
+                assert all(r == [(5, 0, int(ol[n]) - 1, 2.0)] for n, r in enumerate(fused) if ol[n] > 0)
+            lg2, ol = eng.forward(x, lens)
+            lg2[:, :, 7] += 100.0                                # in place: class 7 now wins every frame
+            edited = eng.ctc_greedy(lg2, ol)
+            assert all(r[0][0] == 7 and len(r) == 1 for n, r in enumerate(edited) if ol[n] > 0)
