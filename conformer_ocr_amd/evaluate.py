@@ -48,6 +48,78 @@ class ErrorRate:
         return self.errors / max(self.total, 1)
 
 
+def global_align(seq1: Sequence, seq2: Sequence) -> Tuple[int, List, List]:
+    """Edit-distance alignment of two sequences (the step `kraken.lib.util... global_align(y, x)` performs in the reference's report,
+    cli/test.py:194; kraken is absent here: **parity unpinned**, known-answer tests only): returns (cost, aligned seq1, aligned
+    seq2) of equal length, '' marking a gap; cost = insertions + deletions + substitutions (Needleman-Wunsch with unit costs; on equal
+    cost a diagonal step is preferred, then a deletion from seq1, then an insertion)."""
+    n, m = len(seq1), len(seq2)
+    cost = [[0] * (m + 1) for _ in range(n + 1)]
+    for i in range(1, n + 1):
+        cost[i][0] = i
+    for j in range(1, m + 1):
+        cost[0][j] = j
+    for i in range(1, n + 1):
+        ci, cp, a = cost[i], cost[i - 1], seq1[i - 1]
+        for j in range(1, m + 1):
+            ci[j] = min(cp[j - 1] + (a != seq2[j - 1]), cp[j] + 1, ci[j - 1] + 1)
+    al1, al2 = [], []
+    i, j = n, m
+    while i > 0 or j > 0:
+        if i > 0 and j > 0 and cost[i][j] == cost[i - 1][j - 1] + (seq1[i - 1] != seq2[j - 1]):
+            al1.append(seq1[i - 1]); al2.append(seq2[j - 1]); i -= 1; j -= 1
+        elif i > 0 and cost[i][j] == cost[i - 1][j] + 1:
+            al1.append(seq1[i - 1]); al2.append(''); i -= 1
+        else:
+            al1.append(''); al2.append(seq2[j - 1]); j -= 1
+    return cost[n][m], al1[::-1], al2[::-1]
+
+
+def _script(c: str) -> str:
+    import unicodedata
+    try:
+        return unicodedata.name(c).split()[0].title()
+    except (ValueError, TypeError):
+        return 'Unknown'
+
+
+def compute_confusions(algn_gt: Sequence[str], algn_pred: Sequence[str]):
+    """The tallies of the reference's report (cli/test.py:213, kraken `compute_confusions`; **parity unpinned**): over the aligned
+    ground truth / prediction symbols -- `confusions` {(gt, pred): count} of the differing pairs (gaps as ''), `scripts` {script:
+    characters of the ground truth}, `ins` {script: inserted characters}, `dels` deleted characters, `subs` {script: substituted}."""
+    import collections
+    counts, scripts, ins, subs = collections.Counter(), collections.Counter(), collections.Counter(), collections.Counter()
+    dels = 0
+    for g, p in zip(algn_gt, algn_pred):
+        if g != '':
+            scripts[_script(g)] += 1
+        if g == p:
+            continue
+        counts[(g, p)] += 1
+        if g == '':
+            ins[_script(p)] += 1
+        elif p == '':
+            dels += 1
+        else:
+            subs[_script(g)] += 1
+    return dict(counts.most_common()), dict(scripts), dict(ins), dels, dict(subs)
+
+
+def render_report(model: str, chars: int, errors: int, char_accuracy: float, word_accuracy: float, confusions, scripts, ins, dels, subs) -> str:
+    """Plain-text report with the reference's sections (cli/test.py:214-224: totals, per-script errors, the most frequent confusions)."""
+    out = [f'=== report {model} ===', '', f'{chars}\tCharacters', f'{errors}\tErrors',
+           f'{char_accuracy * 100:.2f}%\tCharacter Accuracy', f'{word_accuracy * 100:.2f}%\tWord Accuracy', '',
+           f'{sum(ins.values())}\tInsertions', f'{dels}\tDeletions', f'{sum(subs.values())}\tSubstitutions', '',
+           'Count\tMissed\t%Right']
+    for scr, cnt in sorted(scripts.items(), key=lambda kv: -kv[1]):
+        miss = subs.get(scr, 0)
+        out.append(f'{cnt}\t{miss}\t{100.0 * (cnt - miss) / max(cnt, 1):.2f}%\t{scr}')
+    out += ['', 'Errors\tCorrect-Generated']
+    for (g, p), cnt in list(confusions.items())[:30]:
+        out.append(f'{cnt}\t{{ {g or "<gap>"} }} - {{ {p or "<gap>"} }}')
+    return '\n'.join(out)
+
+
 def make_batches(widths: Sequence[int], batch_size: int, edge: int = 200) -> List[Tuple[int, List[int]]]:
     """[(padded width, [line indices])]: lines sorted into fixed-edge buckets, widest bucket first (like the reference's
     collate, lines inside a batch are ordered by width descending)."""
@@ -141,14 +213,26 @@ def recognize_crops(net, crops: Sequence[np.ndarray], batch_size: int = 32, edge
     return out
 
 
-def evaluate(net, lines: Sequence[np.ndarray], truths: Sequence[str], **kw) -> Dict[str, float]:
-    """CER / WER of `net` on (lines, truths): the report of cli/test.py:211-212."""
+def evaluate(net, lines: Sequence[np.ndarray], truths: Sequence[str], report: bool = False, model_name: str = 'model', **kw) -> Dict[str, float]:
+    """CER / WER of `net` on (lines, truths): the numbers of cli/test.py:211-212; with `report` also the alignment-based tallies and the
+    rendered text of cli/test.py:194-224 (`confusions`, `insertions`, `deletions`, `substitutions`, `report`)."""
     pred = recognize(net, lines, **kw)
     cer, wer = ErrorRate(False), ErrorRate(True)
     idx = sorted(pred)
     cer.update([pred[i] for i in idx], [truths[i] for i in idx])
     wer.update([pred[i] for i in idx], [truths[i] for i in idx])
-    return {'cer': cer.compute(), 'wer': wer.compute(), 'chars': cer.total, 'lines': len(idx)}
+    out = {'cer': cer.compute(), 'wer': wer.compute(), 'chars': cer.total, 'lines': len(idx)}
+    if report:
+        algn_gt, algn_pred, errors = [], [], 0
+        for i in idx:
+            c, a1, a2 = global_align(truths[i], pred[i])
+            errors += c
+            algn_gt.extend(a1)
+            algn_pred.extend(a2)
+        confusions, scripts, ins, dels, subs = compute_confusions(algn_gt, algn_pred)
+        out.update(errors=errors, confusions=confusions, insertions=ins, deletions=dels, substitutions=subs,
+                   report=render_report(model_name, cer.total, errors, 1.0 - out['cer'], 1.0 - out['wer'], confusions, scripts, ins, dels, subs))
+    return out
 
 
 def validate(net, lines: Sequence[np.ndarray], truths: Sequence[str], batch_size: int = 32, edge: int = 200, rank: int = 0, world: int = 1,

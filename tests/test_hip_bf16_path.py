@@ -247,3 +247,9 @@ def test_bucketed_loop_on_the_wide_model(text_case):
         net = net.to('cuda:0').eval()
         got = recognize(net, tc.lines, batch_size=tc.batch_size, edge=tc.edge)
         assert [got[i] for i in range(tc.n)] == want, dtype
+    # the report of the reference's test loop (cli/test.py:194-224) against the ground truth: no error, no confusion
+    from conformer_ocr_amd.evaluate import evaluate
+    truth = [''.join(x[0] for x in codec.decode([(l, 0, 0, 0.0) for l in s])) for s in tc.texts]
+    rep = evaluate(net, tc.lines, truth, report=True, batch_size=tc.batch_size, edge=tc.edge)
+    assert rep['cer'] == 0.0 and rep['wer'] == 0.0 and rep['errors'] == 0 and rep['confusions'] == {} and rep['lines'] == tc.n
+    assert f"{rep['chars']}\tCharacters" in rep['report']

@@ -180,3 +180,22 @@ def test_average_checkpoints_like_the_reference(tmp_path):
     torch.save({'state_dict': {'other': torch.zeros(1)}}, bad)
     with pytest.raises(KeyError):
         average_checkpoints(paths + [bad], 2)
+
+
+def test_alignment_report_known_answers():
+    """The report of the reference's test loop (cli/test.py:194-224): alignment, confusion tallies, rendered text.  kraken's own
+    functions are absent (parity unpinned): hand-derived cases."""
+    from conformer_ocr_amd.evaluate import compute_confusions, edit_distance, global_align, render_report
+    c, a, b = global_align('kitten', 'sitting')
+    assert c == 3 == edit_distance('kitten', 'sitting') and len(a) == len(b) == 7
+    assert ''.join(a) == 'kitten' and ''.join(b) == 'sitting' and a[-1] == '' and b[-1] == 'g'
+    c, a, b = global_align('abc', 'abc')
+    assert c == 0 and a == b == list('abc')
+    c, a, b = global_align('', 'xy')
+    assert c == 2 and a == ['', ''] and b == ['x', 'y']
+    conf, scripts, ins, dels, subs = compute_confusions(list('kitten') + [''], list('sittin') + ['g'])
+    assert conf == {('k', 's'): 1, ('e', 'i'): 1, ('', 'g'): 1} and scripts == {'Latin': 6} and ins == {'Latin': 1} and dels == 0 and subs == {'Latin': 2}
+    conf, scripts, ins, dels, subs = compute_confusions(['a', 'b', '1'], ['a', '', '7'])
+    assert conf == {('b', ''): 1, ('1', '7'): 1} and dels == 1 and subs == {'Digit': 1} and scripts == {'Latin': 2, 'Digit': 1}
+    rep = render_report('m', 6, 3, 0.5, 0.0, *compute_confusions(list('kitten') + [''], list('sittin') + ['g']))
+    assert '6\tCharacters' in rep and '3\tErrors' in rep and '50.00%\tCharacter Accuracy' in rep and '{ k } - { s }' in rep
