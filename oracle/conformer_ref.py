@@ -77,6 +77,8 @@ class Oracle:
                  fused_frontend: bool = True):
         self.hp = hp
         self.dtype = dtype
+        self.training = False          # train mode (`forward_train`): BatchNorm batch statistics; dropout probabilities 0
+        self.bn_batch_stats: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.bf16 = bool(bf16_operands)
         # bf16 mode: the fused frontend kernel (256 conv channels) also rounds pixels, the 3x3 taps and Z1; the
         # stand-alone conv kernel of the other channel counts keeps those fp32 and rounds Z2 only
@@ -244,11 +246,21 @@ class Oracle:
         t = self._ln_op(y, c + '0')
         a = t @ self.w[c + '2.conv.weight'].squeeze(-1).t() + self.w[c + '2.conv.bias']   # (B,T,2D)
         g = self.r(a[..., :D] * torch.sigmoid(a[..., D:]))
-        s = self.w[c + '5.weight'] / torch.sqrt(self.w[c + '5.running_var'] + BN_EPS)
-        wdw = self.w[c + '4.conv.weight'].squeeze(1) * s.unsqueeze(1)          # (D,k) folded taps
-        bdw = self.w[c + '5.bias'] - self.w[c + '5.running_mean'] * s
         gp = F.pad(g, (0, 0, (k - 1) // 2, (k - 1) // 2))                      # zero rows before/after time
-        u = bdw + sum(gp[:, tau:tau + T, :] * wdw[:, tau] for tau in range(k))
+        if self.training:
+            # nn.BatchNorm1d in train mode (convolution.py:141): statistics over ALL (batch, frame) positions of the padded batch
+            # (no masking anywhere), biased variance for the normalisation; the caller updates the running statistics
+            wraw = self.w[c + '4.conv.weight'].squeeze(1)
+            dwo = sum(gp[:, tau:tau + T, :] * wraw[:, tau] for tau in range(k))
+            mu = dwo.mean((0, 1))
+            var = dwo.var((0, 1), unbiased=False)
+            self.bn_batch_stats[l] = (mu.detach(), var.detach())
+            u = (dwo - mu) / torch.sqrt(var + BN_EPS) * self.w[c + '5.weight'] + self.w[c + '5.bias']
+        else:
+            s = self.w[c + '5.weight'] / torch.sqrt(self.w[c + '5.running_var'] + BN_EPS)
+            wdw = self.w[c + '4.conv.weight'].squeeze(1) * s.unsqueeze(1)      # (D,k) folded taps
+            bdw = self.w[c + '5.bias'] - self.w[c + '5.running_mean'] * s
+            u = bdw + sum(gp[:, tau:tau + T, :] * wdw[:, tau] for tau in range(k))
         u = self.r(F.silu(u))
         out = u @ self.w[c + '7.conv.weight'].squeeze(-1).t() + self.w[c + '7.conv.bias']
         if taps is not None:
@@ -280,6 +292,19 @@ class Oracle:
     def forward(self, line: torch.Tensor, lens, taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """PytorchRecognitionModel.forward (pred.py:118-122): line (N,1,H,W) -> (probits (N,T,ncls), lens int32).
         NO masking anywhere: the padded region takes part."""
+        return self._forward(line, lens, taps)
+
+    def forward_train(self, line: torch.Tensor, lens, taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The training forward of RecognitionModel._step (model.py:129-135): the same modules in train mode -- BatchNorm with batch
+        statistics (`bn_batch_stats[l]` = (mean, biased variance) of block l, for the running-statistics update), dropout
+        probabilities 0 -- with autograd enabled: set `requires_grad_` on the entries of `self.w` and call `.backward()` on a loss."""
+        self.training = True
+        try:
+            return self._forward(line, lens, taps)
+        finally:
+            self.training = False
+
+    def _forward(self, line: torch.Tensor, lens, taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         x = line.squeeze(1)                                                    # (N,H,W); the reference's transpose is a view
         y = self.frontend(x, taps)
         for l in range(self.hp.num_encoder_layers):

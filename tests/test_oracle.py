@@ -125,3 +125,45 @@ def test_text_fixture_pins_both_oracle_modes(text_case, name, lines):
     assert checked >= 0.95 * total
     dev = float((lg16 - lg32).abs().max())
     assert 1e-3 < dev < 0.5, dev                     # the two modes differ by bf16 rounding, not by an indexing error
+
+
+def oracle_train_grads(hp, state, image, lens, targets, dtype=torch.float64):
+    """Loss, probits and d loss / d parameter of the reference's training step through the oracle's train mode + torch autograd."""
+    o = Oracle(hp, state, dtype)
+    params = {k: v for k, v in o.w.items() if v.is_floating_point() and 'running_' not in k}
+    for v in params.values():
+        v.requires_grad_(True)
+    probits, ol = o.forward_train(torch.from_numpy(image).to(dtype), torch.from_numpy(np.asarray(lens)))
+    target = torch.tensor([c for s in targets for c in s], dtype=torch.long)
+    tl = torch.tensor([len(s) for s in targets], dtype=torch.long)
+    loss = torch.nn.functional.ctc_loss(torch.nn.functional.log_softmax(probits, -1).transpose(0, 1), target, ol.long(), tl,
+                                        reduction='sum', zero_infinity=True)                 # model.py:119,136-142
+    loss.backward()
+    return float(loss), probits.detach().numpy(), {k: v.grad.numpy() for k, v in params.items()}, o.bn_batch_stats
+
+
+def test_oracle_train_mode_matches_the_reference_training_step():
+    """tests/golden/tiny_train.npz: the reference encoder in train mode (batch-statistics BatchNorm, dropout 0) + decoder + CTC loss,
+    `loss.backward()` in float64.  The oracle's train mode reproduces the loss, the probits, EVERY parameter gradient and the
+    BatchNorm running statistics the step leaves (momentum 0.1, unbiased batch variance)."""
+    import os
+    from conformer_ocr_amd import synth
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'tiny_train.npz'))
+    hp = synth.hparams('tiny')
+    state = synth.make_state_dict(hp, seed=4321, decoder_gain=1.0)
+    image, lens = synth.make_lines(3, hp.height, 64, seed=4321, widths=[64, 37, 50])
+    loss, probits, grads, bn = oracle_train_grads(hp, state, image, lens, [[3, 1, 4], [1, 5], [9, 2, 6, 5]])
+    assert abs(loss - float(g['loss'])) <= 1e-9 * abs(float(g['loss']))
+    assert np.abs(probits - g['probits']).max() <= 1e-10
+    names = [k[5:] for k in g.files if k.startswith('grad:')]
+    assert sorted(names) == sorted(grads)
+    for k in names:
+        ref = g['grad:' + k]
+        assert np.abs(grads[k].reshape(ref.shape) - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), k
+    M = probits.shape[0] * probits.shape[1]
+    for l, (mu, var) in bn.items():
+        p = f'encoder.layers.{l}.sequential.2.module.sequential.5.'
+        rm = 0.9 * state[p + 'running_mean'].astype(np.float64) + 0.1 * mu.numpy()
+        rv = 0.9 * state[p + 'running_var'].astype(np.float64) + 0.1 * var.numpy() * M / (M - 1)
+        assert np.abs(rm - g['buf:' + p + 'running_mean']).max() <= 1e-9 and np.abs(rv - g['buf:' + p + 'running_var']).max() <= 1e-9
