@@ -46,6 +46,11 @@ SYMBOLS = {
     'cocr_ctc_loss': (_I, [_P, _P, _I, _I, _I, _I32P, _I32P, _I32P, _P, _P, _P]),
     'cocr_decoder_backward': (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     'cocr_decoder_adamw': (_I, [_P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    'cocr_train_begin': (_I, [_P]),
+    'cocr_train_step': (_I, [_P, _P, _I, _I, _I, _I, _I32P, _I32P, _I32P, C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_float), _P]),
+    'cocr_train_get': (_I, [_P, C.c_char_p, _I, _P, C.c_int64, _P]),
+    'cocr_train_adamw': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    'cocr_train_end': (_I, [_P]),
     'cocr_get_tensor': (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
     'cocr_preproc_width': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'cocr_preproc_lines': (_I, [_P, _P, C.POINTER(C.c_int64), _I32P, _I32P, _I32P, _I, _I, _I, _I, _P, _I32P, _P]),

@@ -23,6 +23,7 @@
 #include "ctc.hip.h"
 #include "ctc_loss.hip.h"
 #include "train.hip.h"
+#include "train_enc.hip.h"
 #include "gemm.hip.h"
 #include "ffn.hip.h"
 #include "rowchain_args.hip.h"
@@ -79,6 +80,7 @@ struct BlobPlan {
 struct DevBuf { void *p = nullptr; size_t bytes = 0; };
 
 struct ProfRec { int fam; hipEvent_t a, b; };
+struct TrainState;
 
 struct cocr_model {
     cocr_hparams hp;
@@ -152,6 +154,7 @@ struct cocr_model {
     std::map<std::string, std::pair<float *, int64_t>> taps;
     float *tapbuf = nullptr;     // debug: 4 fp32 (M, D) tap targets of the chain kernels' TAPS instantiation + one bf16 (M, D)
     size_t tapbuf_rows = 0;
+    TrainState *train = nullptr;   // cocr_train_begin .. cocr_train_end (train_api.hip.h)
     bool profile = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -258,9 +261,11 @@ static void clear_taps(cocr_model *m) {
     if (m->tapbuf) { (void)hipFree(m->tapbuf); m->tapbuf = nullptr; m->tapbuf_rows = 0; }
 }
 
+static void train_free(cocr_model *m);
 extern "C" void cocr_destroy(cocr_model *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    train_free(m);
     free_workspace(m);
     clear_taps(m);
     if (m->blob) (void)hipFree(m->blob);
@@ -1605,3 +1610,5 @@ extern "C" int cocr_set_graph(cocr_model *m, int on) {
     m->use_graph = on != 0;
     return COCR_OK;
 }
+
+#include "train_api.hip.h"

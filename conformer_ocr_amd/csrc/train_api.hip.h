@@ -1,0 +1,443 @@
+// Training step of the whole network behind the C ABI (included at the end of cocr_api.hip):
+//     cocr_train_begin      fp32 master copy of every parameter / buffer (reference state-dict names) on the device, zeroed AdamW state
+//     cocr_train_step       RecognitionModel.training_step (model.py:129-152): train-mode forward (batch-statistics BatchNorm, dropout at the
+//                           reference's six sites), CTC criterion, backward through decoder AND encoder -> the gradient of every parameter
+//     cocr_train_adamw      torch.optim.AdamW over all parameters (model.py:283-284)
+//     cocr_train_get        a parameter / buffer / gradient by name (checkpointing, tests)
+//     cocr_train_end        the trained values back into the model's state (re-finalize to serve them)
+// fp32 and correctness-first (train_enc.hip.h); every matrix product -- forward, input gradient, weight gradient -- is the exact-fp32 MFMA GEMM
+// of gemm.hip.h: Y = X W^T directly, dX = dY (W^T)^T and dW = dY^T (X^T)^T through explicit transposes.  The inference path (bf16 row
+// chains, fused frontend) is not touched: training keeps its own activations (everything the backward needs is stored; nothing is recomputed
+// except dropout masks, which are regenerated from (seed, site, index)).
+#pragma once
+
+struct TrainEntry { size_t off = 0, n = 0; bool param = false; };
+
+struct TrainState {
+    std::map<std::string, TrainEntry> idx;
+    std::vector<std::string> order;
+    size_t nparam = 0, ntotal = 0;            // floats: parameters first (the optimizer's range), then buffers (BatchNorm running statistics)
+    float *P = nullptr, *G = nullptr, *Mo = nullptr, *Vo = nullptr;
+    long step = 0;
+    unsigned char *ws = nullptr;              // activations + scratch of one step
+    size_t ws_bytes = 0;
+    float *pe = nullptr;                      // sinusoid rows for relative positions T-1 ... -(T-1), (2T-1, D)
+    int peT = 0;
+};
+
+static void train_free(cocr_model *m) {
+    TrainState *t = m->train;
+    if (!t) return;
+    for (void *p : {(void *)t->P, (void *)t->G, (void *)t->Mo, (void *)t->Vo, (void *)t->ws, (void *)t->pe})
+        if (p) (void)hipFree(p);
+    delete t;
+    m->train = nullptr;
+}
+
+static bool train_is_buffer(const std::string &n) { return n.find("running_mean") != std::string::npos || n.find("running_var") != std::string::npos; }
+
+extern "C" int cocr_train_begin(cocr_model *m) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    train_free(m);
+    TrainState *t = new TrainState();
+    m->train = t;
+    for (int pass = 0; pass < 2; ++pass) {        // parameters, then buffers
+        for (auto &n : m->names) {
+            const HostTensor &h = m->host[n];
+            if (!h.set) { train_free(m); return fail(COCR_ESTATE, "missing tensor '%s'", n.c_str()); }
+            if (train_is_buffer(n) != (pass == 1)) continue;
+            TrainEntry e;
+            e.off = t->ntotal; e.n = h.data.size(); e.param = pass == 0;
+            t->ntotal += (e.n + 3) / 4 * 4;              // 16-byte aligned tensors
+            t->idx[n] = e;
+            t->order.push_back(n);
+        }
+        if (pass == 0) t->nparam = t->ntotal;
+    }
+    std::vector<float> flat(t->ntotal, 0.f);
+    for (auto &kv : t->idx) memcpy(flat.data() + kv.second.off, m->host[kv.first].data.data(), kv.second.n * 4);
+    HIP_TRY(hipMalloc((void **)&t->P, t->ntotal * 4));
+    HIP_TRY(hipMalloc((void **)&t->G, t->nparam * 4));
+    HIP_TRY(hipMalloc((void **)&t->Mo, t->nparam * 4));
+    HIP_TRY(hipMalloc((void **)&t->Vo, t->nparam * 4));
+    HIP_TRY(hipMemcpy(t->P, flat.data(), t->ntotal * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(t->G, 0, t->nparam * 4));
+    HIP_TRY(hipMemset(t->Mo, 0, t->nparam * 4));
+    HIP_TRY(hipMemset(t->Vo, 0, t->nparam * 4));
+    return COCR_OK;
+}
+
+// kind: 0 = value (parameter or buffer), 1 = gradient of the last cocr_train_step
+extern "C" int cocr_train_get(cocr_model *m, const char *name, int kind, float *host_out, int64_t n_elems, void *stream) {
+    if (!m || !name || !host_out) return fail(COCR_EINVAL, "null argument");
+    TrainState *t = m->train;
+    if (!t) return fail(COCR_ESTATE, "cocr_train_begin has not been called");
+    auto it = t->idx.find(name);
+    if (it == t->idx.end()) return fail(COCR_EINVAL, "unknown tensor '%s'", name);
+    if ((size_t)n_elems != it->second.n) return fail(COCR_EINVAL, "tensor '%s' has %zu elements", name, it->second.n);
+    if (kind == 1 && !it->second.param) return fail(COCR_EINVAL, "'%s' is a buffer: no gradient", name);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(host_out, (kind == 1 ? t->G : t->P) + it->second.off, it->second.n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return COCR_OK;
+}
+
+extern "C" int cocr_train_end(cocr_model *m) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    TrainState *t = m->train;
+    if (!t) return fail(COCR_ESTATE, "cocr_train_begin has not been called");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> flat(t->ntotal);
+    HIP_TRY(hipMemcpy(flat.data(), t->P, t->ntotal * 4, hipMemcpyDeviceToHost));
+    for (auto &kv : t->idx) memcpy(m->host[kv.first].data.data(), flat.data() + kv.second.off, kv.second.n * 4);
+    train_free(m);
+    return COCR_OK;
+}
+
+extern "C" int cocr_train_adamw(cocr_model *m, float lr, float beta1, float beta2, float eps, float weight_decay, void *stream) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    TrainState *t = m->train;
+    if (!t) return fail(COCR_ESTATE, "cocr_train_begin has not been called");
+    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f) || !(weight_decay >= 0.f))
+        return fail(COCR_EINVAL, "invalid AdamW hyper-parameters");
+    HIP_TRY(hipSetDevice(m->device));
+    t->step += 1;
+    const float bc1 = 1.0f - powf(beta1, (float)t->step), bc2 = 1.0f - powf(beta2, (float)t->step);
+    hipLaunchKernelGGL(k_adamw_flat, dim3(1024), dim3(256), 0, (hipStream_t)stream, t->P, t->G, t->Mo, t->Vo, t->nparam, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    LAUNCH_CHECK();
+    return COCR_OK;
+}
+
+// dropout_p: {input, feed_forward, attention, conv} (the reference's four probabilities, encoder.py:144-147); loss_out (host): the summed CTC loss
+extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W, const int32_t *in_lens, const int32_t *targets,
+                               const int32_t *label_lens, const float *dropout_p, uint64_t seed, float *loss_out, void *stream) {
+    if (!m || !lines || !in_lens || !label_lens || !loss_out) return fail(COCR_EINVAL, "null argument");
+    TrainState *t = m->train;
+    if (!t) return fail(COCR_ESTATE, "cocr_train_begin has not been called");
+    if (H != m->H) return fail(COCR_EINVAL, "line height %d does not match the model's height %d", H, m->H);
+    if (N < 1 || W < 1) return fail(COCR_EINVAL, "empty batch");
+    if (line_dtype != COCR_F32 && line_dtype != COCR_U8) return fail(COCR_EINVAL, "line dtype must be COCR_F32 or COCR_U8");
+    const float p_in = dropout_p ? dropout_p[0] : 0.f, p_ff = dropout_p ? dropout_p[1] : 0.f, p_at = dropout_p ? dropout_p[2] : 0.f, p_cv = dropout_p ? dropout_p[3] : 0.f;
+    for (float p : {p_in, p_ff, p_at, p_cv}) if (!(p >= 0.f && p < 1.f)) return fail(COCR_EINVAL, "dropout probability outside [0, 1)");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int D = m->D, C = m->C, L = m->L, Hh = m->heads, dh = m->dh, ff = m->ff, K = m->ksz, ncls = m->ncls, snum = m->snum;
+    const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
+
+    // ---- shapes of the frontend stages
+    std::vector<int> Ts(snum), Fs(snum);
+    { int tt = W, f = H; for (int i = 0; i < snum; ++i) { tt = out_len1(tt); f = out_len1(f); Ts[i] = tt; Fs[i] = f; } }
+    const int T = Ts.back(), F = Fs.back(), M = N * T, Mp = round_up(M, 32), R = 2 * T - 1, Rp = round_up(R, 32);
+    const int nclp = round_up(ncls, 4);
+    std::vector<int32_t> out_lens(N);
+    for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
+
+    // ---- workspace: one bump allocation, (re)sized for this shape
+    size_t need = 0;
+    auto rsv = [&](size_t floats) { size_t o = need; need += (floats * 4 + 255) / 256 * 256; return o; };
+    struct Stage { size_t z2, z3; };
+    struct Lay {
+        size_t x_in, xn1, mu1, rs1, h1, a1, x1, xn2, mu2, rs2, q, k, v, P, attn, ctx, x2, xn3, mu3, rs3, ga, g, dwo, bnm, bnr, xhat, bny, sact, x3, xn4, mu4, rs4, h4, a4, x4, mu5, rs5;
+    };
+    const size_t oX = rsv((size_t)N * H * W);
+    const size_t oZ1 = rsv((size_t)N * Ts[0] * Fs[0] * C);
+    std::vector<Stage> stg(snum - 1);
+    for (int i = 0; i + 1 < snum; ++i) { const size_t rows = (size_t)N * Ts[i + 1] * Fs[i + 1]; stg[i].z2 = rsv(rows * C); stg[i].z3 = rsv(rows * C); }
+    const size_t oZt = rsv((size_t)M * C * F);
+    std::vector<Lay> lay(L);
+    const size_t MD = (size_t)M * D;
+    for (int l = 0; l < L; ++l) {
+        Lay &a = lay[l];
+        a.x_in = rsv(MD); a.xn1 = rsv(MD); a.mu1 = rsv(M); a.rs1 = rsv(M); a.h1 = rsv((size_t)M * ff); a.a1 = rsv((size_t)M * ff); a.x1 = rsv(MD);
+        a.xn2 = rsv(MD); a.mu2 = rsv(M); a.rs2 = rsv(M); a.q = rsv(MD); a.k = rsv(MD); a.v = rsv(MD); a.P = rsv((size_t)R * D);
+        a.attn = rsv((size_t)N * Hh * T * T); a.ctx = rsv(MD); a.x2 = rsv(MD);
+        a.xn3 = rsv(MD); a.mu3 = rsv(M); a.rs3 = rsv(M); a.ga = rsv(2 * MD); a.g = rsv(MD); a.dwo = rsv(MD); a.bnm = rsv(D); a.bnr = rsv(D); a.xhat = rsv(MD);
+        a.bny = rsv(MD); a.sact = rsv(MD); a.x3 = rsv(MD);
+        a.xn4 = rsv(MD); a.mu4 = rsv(M); a.rs4 = rsv(M); a.h4 = rsv((size_t)M * ff); a.a4 = rsv((size_t)M * ff); a.x4 = rsv(MD); a.mu5 = rsv(M); a.rs5 = rsv(M);
+    }
+    const size_t oXout = rsv(MD);                              // encoder output (after the last block's LayerNorm)
+    const size_t oLogits = rsv((size_t)M * ncls), oDlog = rsv((size_t)M * ncls), oDlogP = rsv((size_t)M * nclp), oNll = rsv(N);
+    // backward scratch
+    size_t big_rows = (size_t)M;
+    for (int i = 0; i + 1 < snum; ++i) big_rows = std::max(big_rows, (size_t)N * Ts[i + 1] * Fs[i + 1]);
+    const size_t big_rows_p = (big_rows + 31) / 32 * 32;
+    const int wide = std::max(std::max(ff, 3 * D), std::max(C * F, std::max(2 * D, nclp)));
+    const size_t tr_floats = std::max((size_t)wide * Mp, big_rows_p * (size_t)C);
+    const size_t oTA = rsv(tr_floats), oTB = rsv(tr_floats), oTW = rsv((size_t)std::max(std::max((size_t)ff * D, (size_t)C * F * D), (size_t)std::max(C * C, D * nclp)) + 1024);
+    const size_t oDa = rsv(MD), oDb = rsv(MD), oDc = rsv(MD), oDd = rsv(MD), oDe = rsv(MD), oDwide = rsv((size_t)M * std::max(ff, 2 * D)), oDwide2 = rsv((size_t)M * std::max(ff, 2 * D));
+    const size_t oDsb = rsv((size_t)N * Hh * T * T), oDP = rsv((size_t)Rp * D);
+    const size_t oZg = rsv((size_t)M * C * F), oZa = rsv(big_rows * C), oZb = rsv(big_rows * C), oZ1g = rsv((size_t)N * Ts[0] * Fs[0] * C);
+    const size_t part_floats = std::max((size_t)ceil_div((int)std::min<size_t>(big_rows, 1u << 30), COCR_CS_ROWS) * (size_t)std::max(wide, C * 10),
+                                        (size_t)ceil_div((int)std::min<size_t>((size_t)N * Ts[0] * Fs[0], 1u << 30), COCR_CV_POS) * 10 * (size_t)C);
+    const size_t oPart = rsv(part_floats + 4096), oVec = rsv(4 * (size_t)std::max(D, C) + 64);
+    if (need > t->ws_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (t->ws) (void)hipFree(t->ws);
+        t->ws = nullptr; t->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&t->ws, need));
+        t->ws_bytes = need;
+    }
+    auto WS = [&](size_t off) { return reinterpret_cast<float *>(t->ws + off); };
+    auto Pp = [&](const std::string &n) -> float * { return t->P + t->idx.at(n).off; };
+    auto Gp = [&](const std::string &n) -> float * { return t->G + t->idx.at(n).off; };
+    auto grid1 = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)); };
+    char nb[256];
+    auto key = [&](int l, const char *suffix) { snprintf(nb, sizeof nb, "encoder.layers.%d.sequential.%s", l, suffix); return std::string(nb); };
+
+    // ---- primitives
+    auto gemm = [&](const float *A, int lda, const float *Wt, int ldw, int Mr, int Nc, int Kr, float *out, int ldo, const float *bias) -> int {
+        EpiStoreF32 e{out, ldo, bias, Nc};
+        GEMM_TRY(launch_gemm<float>(s, A, lda, Wt, ldw, Mr, Nc, Kr, e));
+        return COCR_OK;
+    };
+    auto transpose = [&](const float *in, float *out, int Rr, int Cc, int ldo) {      // out (Cc, ldo) zero-padded beyond Rr
+        (void)hipMemsetAsync(out, 0, (size_t)Cc * ldo * 4, s);
+        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(Cc, 32), ceil_div(Rr, 32)), dim3(256), 0, s, in, out, Rr, Cc, ldo);
+    };
+    auto colsum = [&](const float *a, const float *b, int Mr, int Nc, float *out, int accumulate) {
+        const int chunks = ceil_div(Mr, COCR_CS_ROWS);
+        hipLaunchKernelGGL(k_colsum_partial, dim3(ceil_div(Nc, 256), chunks), dim3(256), 0, s, a, b, WS(oPart), Mr, Nc);
+        hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 256)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
+    };
+    // Y (rows, Nc) = X (rows, Kr) W(Nc, Kr)^T + b
+    auto lin_fwd = [&](const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *Y) -> int {
+        return gemm(X, Kr, Pp(w), Kr, rows, Nc, Kr, Y, Nc, b.empty() ? nullptr : Pp(b));
+    };
+    // dW += dY^T X, db += colsum(dY), dX = dY W   (dX null: not wanted).  dY (rows, Nc), X (rows, Kr)
+    auto lin_bwd = [&](const float *dY, const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *dX) -> int {
+        const int rp = round_up(rows, 32);
+        int r;
+        transpose(dY, WS(oTA), rows, Nc, rp);
+        transpose(X, WS(oTB), rows, Kr, rp);
+        if ((r = gemm(WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, Gp(w), Kr, nullptr))) return r;
+        if (!b.empty()) colsum(dY, nullptr, rows, Nc, Gp(b), 0);
+        if (dX) {
+            const int np = round_up(Nc, 4);
+            const float *dYp = dY;
+            if (np != Nc) { hipLaunchKernelGGL(k_pad_cols, grid1((size_t)rows * np), dim3(256), 0, s, dY, WS(oDlogP), rows, Nc, np); dYp = WS(oDlogP); }
+            transpose(Pp(w), WS(oTW), Nc, Kr, np);                      // W^T (Kr, np)
+            if ((r = gemm(dYp, np, WS(oTW), np, rows, Kr, np, dX, Kr, nullptr))) return r;
+        }
+        return COCR_OK;
+    };
+    auto ln_fwd = [&](const float *x, const std::string &g, const std::string &b, float *y, float *mu, float *rs) {
+        hipLaunchKernelGGL(k_ln_fwd, dim3(ceil_div(M, 4)), dim3(256), 0, s, x, Pp(g), Pp(b), y, mu, rs, M, D);
+    };
+    // dx (+)= LayerNorm backward of dy; d gamma, d beta
+    auto ln_bwd = [&](const float *dy, const float *x, const float *mu, const float *rs, const std::string &g, const std::string &b, float *dx, int accumulate) {
+        hipLaunchKernelGGL(k_ln_bwd, dim3(ceil_div(M, 4)), dim3(256), 0, s, dy, x, mu, rs, Pp(g), dx, WS(oDwide2), M, D, accumulate);
+        colsum(WS(oDwide2), nullptr, M, D, Gp(g), 0);
+        colsum(dy, nullptr, M, D, Gp(b), 0);
+    };
+    auto dropout = [&](float *x, size_t n, float p, unsigned site) {
+        if (p > 0.f) hipLaunchKernelGGL(k_dropout, grid1(n), dim3(256), 0, s, x, n, p, (unsigned long long)seed, site);
+    };
+    auto copy = [&](float *dst, const float *src, size_t n) { (void)hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, s); };
+    int rc;
+
+    // ---- positional rows PE(p), p = T-1 ... -(T-1) (embedding.py:35-56,66), cached per T
+    if (t->peT != T) {
+        if (t->pe) (void)hipFree(t->pe);
+        t->pe = nullptr;
+        std::vector<float> pe((size_t)R * D);
+        for (int r = 0; r < R; ++r) {
+            const float pos = (float)(T - 1 - r);
+            for (int i = 0; i < D; i += 2) {
+                const float div = expf((float)i * (float)(-(log(10000.0) / D)));
+                pe[(size_t)r * D + i] = sinf(pos * div);
+                if (i + 1 < D) pe[(size_t)r * D + i + 1] = cosf(pos * div);
+            }
+        }
+        HIP_TRY(hipMalloc((void **)&t->pe, pe.size() * 4));
+        HIP_TRY(hipMemcpy(t->pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+        t->peT = T;
+    }
+    HIP_TRY(hipMemsetAsync(t->G, 0, t->nparam * 4, s));
+
+    // =========================================================================================== forward (train mode)
+    float *X = WS(oX);
+    if (line_dtype == COCR_U8) hipLaunchKernelGGL(k_u8_to_f32, grid1((size_t)N * H * W), dim3(256), 0, s, (const uint8_t *)lines, X, (size_t)N * H * W);
+    else copy(X, (const float *)lines, (size_t)N * H * W);
+    hipLaunchKernelGGL(k_conv0_fwd, grid1((size_t)N * Ts[0] * Fs[0] * C), dim3(256), 0, s, X, Pp("encoder.conv_subsample.conv.0.weight"),
+                       Pp("encoder.conv_subsample.conv.0.bias"), WS(oZ1), N, H, W, Ts[0], Fs[0], C);
+    auto conv_name = [&](int idx, const char *leaf) { snprintf(nb, sizeof nb, "encoder.conv_subsample.conv.%d.%s", idx, leaf); return std::string(nb); };
+    {
+        const float *zin = WS(oZ1);
+        for (int i = 0, idx = 2; i + 1 < snum; ++i, idx += 3) {
+            const size_t rows = (size_t)N * Ts[i + 1] * Fs[i + 1];
+            hipLaunchKernelGGL(k_dw3_fwd, grid1(rows * C), dim3(256), 0, s, zin, Pp(conv_name(idx, "weight")), Pp(conv_name(idx, "bias")), WS(stg[i].z2),
+                               N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
+            if ((rc = lin_fwd(WS(stg[i].z2), conv_name(idx + 1, "weight"), conv_name(idx + 1, "bias"), (int)rows, C, C, WS(stg[i].z3)))) return rc;
+            hipLaunchKernelGGL(k_relu, grid1(rows * C), dim3(256), 0, s, WS(stg[i].z3), rows * C);
+            zin = WS(stg[i].z3);
+        }
+        hipLaunchKernelGGL(k_tfc_to_tcf, grid1((size_t)M * F * C), dim3(256), 0, s, zin, WS(oZt), (size_t)M, F, C, 0);
+    }
+    if ((rc = lin_fwd(WS(oZt), "encoder.conv_subsample.out.0.weight", "encoder.conv_subsample.out.0.bias", M, D, C * F, WS(lay[0].x_in)))) return rc;
+    dropout(WS(lay[0].x_in), MD, p_in, 1);
+    const float scale = 1.0f / sqrtf((float)dh);
+    const long long arows = (long long)N * Hh * T;
+    auto ffn_fwd = [&](int l, int which, const float *xin, size_t oxn, size_t omu, size_t ors, size_t oh, size_t oa, float *xout) -> int {
+        const std::string pre = std::string(which == 0 ? "0" : "3") + ".module.sequential.";
+        ln_fwd(xin, key(l, (pre + "0.weight").c_str()), key(l, (pre + "0.bias").c_str()), WS(oxn), WS(omu), WS(ors));
+        int r;
+        if ((r = lin_fwd(WS(oxn), key(l, (pre + "1.linear.weight").c_str()), key(l, (pre + "1.linear.bias").c_str()), M, ff, D, WS(oh)))) return r;
+        hipLaunchKernelGGL(k_silu_fwd, grid1((size_t)M * ff), dim3(256), 0, s, WS(oh), WS(oa), (size_t)M * ff);
+        dropout(WS(oa), (size_t)M * ff, p_ff, 16 * l + 2 + 8 * which);
+        if ((r = lin_fwd(WS(oa), key(l, (pre + "4.linear.weight").c_str()), key(l, (pre + "4.linear.bias").c_str()), M, D, ff, WS(oDa)))) return r;
+        dropout(WS(oDa), MD, p_ff, 16 * l + 3 + 8 * which);
+        hipLaunchKernelGGL(k_add3, grid1(MD), dim3(256), 0, s, xout, xin, WS(oDa), ffr, MD);
+        return COCR_OK;
+    };
+    for (int l = 0; l < L; ++l) {
+        Lay &a = lay[l];
+        if ((rc = ffn_fwd(l, 0, WS(a.x_in), a.xn1, a.mu1, a.rs1, a.h1, a.a1, WS(a.x1)))) return rc;
+        // MHSA
+        ln_fwd(WS(a.x1), key(l, "1.module.layer_norm.weight"), key(l, "1.module.layer_norm.bias"), WS(a.xn2), WS(a.mu2), WS(a.rs2));
+        if ((rc = lin_fwd(WS(a.xn2), key(l, "1.module.attention.query_proj.linear.weight"), key(l, "1.module.attention.query_proj.linear.bias"), M, D, D, WS(a.q)))) return rc;
+        if ((rc = lin_fwd(WS(a.xn2), key(l, "1.module.attention.key_proj.linear.weight"), key(l, "1.module.attention.key_proj.linear.bias"), M, D, D, WS(a.k)))) return rc;
+        if ((rc = lin_fwd(WS(a.xn2), key(l, "1.module.attention.value_proj.linear.weight"), key(l, "1.module.attention.value_proj.linear.bias"), M, D, D, WS(a.v)))) return rc;
+        if ((rc = lin_fwd(t->pe, key(l, "1.module.attention.pos_proj.linear.weight"), "", R, D, D, WS(a.P)))) return rc;
+        hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)((arows + 3) / 4)), dim3(256), 4 * 2 * dh * 4, s, WS(a.q), WS(a.k), WS(a.v), WS(a.P),
+                           Pp(key(l, "1.module.attention.u_bias")), Pp(key(l, "1.module.attention.v_bias")), WS(a.attn), WS(a.ctx), arows, T, Hh, dh, scale,
+                           p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
+        if ((rc = lin_fwd(WS(a.ctx), key(l, "1.module.attention.out_proj.linear.weight"), key(l, "1.module.attention.out_proj.linear.bias"), M, D, D, WS(oDa)))) return rc;
+        dropout(WS(oDa), MD, p_at, 16 * l + 5);
+        hipLaunchKernelGGL(k_add3, grid1(MD), dim3(256), 0, s, WS(a.x2), WS(a.x1), WS(oDa), 1.0f, MD);
+        // conv module
+        ln_fwd(WS(a.x2), key(l, "2.module.sequential.0.weight"), key(l, "2.module.sequential.0.bias"), WS(a.xn3), WS(a.mu3), WS(a.rs3));
+        if ((rc = lin_fwd(WS(a.xn3), key(l, "2.module.sequential.2.conv.weight"), key(l, "2.module.sequential.2.conv.bias"), M, 2 * D, D, WS(a.ga)))) return rc;
+        hipLaunchKernelGGL(k_glu_fwd, grid1(MD), dim3(256), 0, s, WS(a.ga), WS(a.g), M, D);
+        hipLaunchKernelGGL(k_dw1d_fwd, grid1(MD), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K);
+        colsum(WS(a.dwo), nullptr, M, D, WS(oVec), 0);
+        colsum(WS(a.dwo), WS(a.dwo), M, D, WS(oVec) + D, 0);
+        hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(D, 256)), dim3(256), 0, s, WS(oVec), WS(oVec) + D, M, D, WS(a.bnm), WS(a.bnr),
+                           Pp(key(l, "2.module.sequential.5.running_mean")), Pp(key(l, "2.module.sequential.5.running_var")), 0.1f);
+        hipLaunchKernelGGL(k_bn_apply, grid1(MD), dim3(256), 0, s, WS(a.dwo), WS(a.bnm), WS(a.bnr), Pp(key(l, "2.module.sequential.5.weight")),
+                           Pp(key(l, "2.module.sequential.5.bias")), WS(a.xhat), WS(a.bny), M, D);
+        hipLaunchKernelGGL(k_silu_fwd, grid1(MD), dim3(256), 0, s, WS(a.bny), WS(a.sact), MD);
+        if ((rc = lin_fwd(WS(a.sact), key(l, "2.module.sequential.7.conv.weight"), key(l, "2.module.sequential.7.conv.bias"), M, D, D, WS(oDa)))) return rc;
+        dropout(WS(oDa), MD, p_cv, 16 * l + 6);
+        hipLaunchKernelGGL(k_add3, grid1(MD), dim3(256), 0, s, WS(a.x3), WS(a.x2), WS(oDa), 1.0f, MD);
+        if ((rc = ffn_fwd(l, 1, WS(a.x3), a.xn4, a.mu4, a.rs4, a.h4, a.a4, WS(a.x4)))) return rc;
+        float *xnext = l + 1 < L ? WS(lay[l + 1].x_in) : WS(oXout);
+        ln_fwd(WS(a.x4), key(l, "4.weight"), key(l, "4.bias"), xnext, WS(a.mu5), WS(a.rs5));
+    }
+    if ((rc = lin_fwd(WS(oXout), "decoder.weight", "decoder.bias", M, ncls, D, WS(oLogits)))) return rc;
+    LAUNCH_CHECK();
+    // ---- criterion (model.py:119,136-142): summed CTC loss and d loss / d probits
+    if ((rc = cocr_ctc_loss(m, WS(oLogits), N, T, ncls, out_lens.data(), targets, label_lens, WS(oNll), WS(oDlog), stream))) return rc;
+    {
+        std::vector<float> nll(N);
+        HIP_TRY(hipMemcpyAsync(nll.data(), WS(oNll), (size_t)N * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        double sum = 0.0;
+        for (float v : nll) sum += v;
+        *loss_out = (float)sum;
+    }
+
+    // =========================================================================================== backward
+    float *dx = WS(oDb);                                    // gradient of the stream entering the current point
+    if ((rc = lin_bwd(WS(oDlog), WS(oXout), "decoder.weight", "decoder.bias", M, ncls, D, dx))) return rc;
+    auto ffn_bwd = [&](int l, int which, const float *xin, size_t oxn, size_t omu, size_t ors, size_t oh, size_t oa, float *dxio) -> int {
+        // x_out = x_in + ffr drop(W2 drop(silu(W1 LN(x_in) + b1)) + b2): dxio holds d x_out on entry, d x_in on exit
+        const std::string pre = std::string(which == 0 ? "0" : "3") + ".module.sequential.";
+        float *dob = WS(oDa);
+        (void)hipMemsetAsync(dob, 0, MD * 4, s);
+        hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, dob, dxio, ffr, MD);
+        dropout(dob, MD, p_ff, 16 * l + 3 + 8 * which);
+        int r;
+        if ((r = lin_bwd(dob, WS(oa), key(l, (pre + "4.linear.weight").c_str()), key(l, (pre + "4.linear.bias").c_str()), M, D, ff, WS(oDwide)))) return r;
+        dropout(WS(oDwide), (size_t)M * ff, p_ff, 16 * l + 2 + 8 * which);
+        hipLaunchKernelGGL(k_silu_bwd, grid1((size_t)M * ff), dim3(256), 0, s, WS(oh), WS(oDwide), (size_t)M * ff);
+        if ((r = lin_bwd(WS(oDwide), WS(oxn), key(l, (pre + "1.linear.weight").c_str()), key(l, (pre + "1.linear.bias").c_str()), M, ff, D, WS(oDc)))) return r;
+        ln_bwd(WS(oDc), xin, WS(omu), WS(ors), key(l, (pre + "0.weight").c_str()), key(l, (pre + "0.bias").c_str()), dxio, 1);
+        return COCR_OK;
+    };
+    for (int l = L - 1; l >= 0; --l) {
+        Lay &a = lay[l];
+        // block-final LayerNorm (encoder.py:99)
+        ln_bwd(dx, WS(a.x4), WS(a.mu5), WS(a.rs5), key(l, "4.weight"), key(l, "4.bias"), WS(oDd), 0);
+        dx = WS(oDd);
+        if ((rc = ffn_bwd(l, 1, WS(a.x3), a.xn4, a.mu4, a.rs4, a.h4, a.a4, dx))) return rc;
+        // conv module: x3 = x2 + drop(pw2(silu(bn(dw(glu(pw1(LN(x2))))))))
+        {
+            float *dob = WS(oDa);
+            copy(dob, dx, MD);
+            dropout(dob, MD, p_cv, 16 * l + 6);
+            if ((rc = lin_bwd(dob, WS(a.sact), key(l, "2.module.sequential.7.conv.weight"), key(l, "2.module.sequential.7.conv.bias"), M, D, D, WS(oDc)))) return rc;
+            hipLaunchKernelGGL(k_silu_bwd, grid1(MD), dim3(256), 0, s, WS(a.bny), WS(oDc), MD);               // d bn_y
+            colsum(WS(oDc), nullptr, M, D, WS(oVec), 0);                                                      // sum dy   = d beta
+            colsum(WS(oDc), WS(a.xhat), M, D, WS(oVec) + D, 0);                                               // sum dy xhat = d gamma
+            copy(Gp(key(l, "2.module.sequential.5.bias")), WS(oVec), D);
+            copy(Gp(key(l, "2.module.sequential.5.weight")), WS(oVec) + D, D);
+            hipLaunchKernelGGL(k_bn_bwd, grid1(MD), dim3(256), 0, s, WS(oDc), WS(a.xhat), Pp(key(l, "2.module.sequential.5.weight")), WS(a.bnr), WS(oVec),
+                               WS(oVec) + D, WS(oDe), M, D);                                                  // d dwo
+            hipLaunchKernelGGL(k_dw1d_bwd_w, dim3(ceil_div(D, 64), K), dim3(64), 0, s, WS(oDe), WS(a.g), Gp(key(l, "2.module.sequential.4.conv.weight")), N, T, D, K);
+            hipLaunchKernelGGL(k_dw1d_bwd_in, grid1(MD), dim3(256), 0, s, WS(oDe), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(oDc), N, T, D, K);   // d g
+            hipLaunchKernelGGL(k_glu_bwd, grid1(MD), dim3(256), 0, s, WS(a.ga), WS(oDc), WS(oDwide), M, D);                                              // d a (M, 2D)
+            if ((rc = lin_bwd(WS(oDwide), WS(a.xn3), key(l, "2.module.sequential.2.conv.weight"), key(l, "2.module.sequential.2.conv.bias"), M, 2 * D, D, WS(oDc)))) return rc;
+            ln_bwd(WS(oDc), WS(a.x2), WS(a.mu3), WS(a.rs3), key(l, "2.module.sequential.0.weight"), key(l, "2.module.sequential.0.bias"), dx, 1);
+        }
+        // MHSA: x2 = x1 + drop(out_proj(attention(LN(x1))))
+        {
+            float *dob = WS(oDa);
+            copy(dob, dx, MD);
+            dropout(dob, MD, p_at, 16 * l + 5);
+            if ((rc = lin_bwd(dob, WS(a.ctx), key(l, "1.module.attention.out_proj.linear.weight"), key(l, "1.module.attention.out_proj.linear.bias"), M, D, D, WS(oDc)))) return rc;   // d ctx
+            float *du_part = WS(oDwide), *dvb_part = WS(oDwide) + MD;
+            const float *ub = Pp(key(l, "1.module.attention.u_bias")), *vbp = Pp(key(l, "1.module.attention.v_bias"));
+            hipLaunchKernelGGL(k_attn_bwd_rows, dim3((unsigned)((arows + 3) / 4)), dim3(256), 4 * dh * 4, s, WS(oDc), WS(a.k), WS(a.v), WS(a.P), WS(a.attn), WS(oDsb),
+                               du_part, dvb_part, arows, T, Hh, dh, scale, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
+            hipLaunchKernelGGL(k_attn_bwd_cols, dim3((unsigned)((arows + 3) / 4)), dim3(256), 0, s, WS(oDc), WS(a.q), ub, WS(a.attn), WS(oDsb), WS(oDe), WS(oDa),
+                               arows, T, Hh, dh, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));            // d k -> oDe, d v -> oDa
+            (void)hipMemsetAsync(WS(oDP), 0, (size_t)Rp * D * 4, s);
+            hipLaunchKernelGGL(k_attn_bwd_pos, dim3(ceil_div(R * Hh, 4)), dim3(256), 0, s, WS(a.q), vbp, WS(oDsb), WS(oDP), N, T, Hh, dh);
+            colsum(du_part, nullptr, M, D, Gp(key(l, "1.module.attention.u_bias")), 0);
+            colsum(dvb_part, nullptr, M, D, Gp(key(l, "1.module.attention.v_bias")), 0);
+            hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, du_part, dvb_part, 1.0f, MD);                 // d q
+            // pos_proj weight: P = PE Wpos^T  ->  d Wpos = dP^T PE
+            if ((rc = lin_bwd(WS(oDP), t->pe, key(l, "1.module.attention.pos_proj.linear.weight"), "", R, D, D, nullptr))) return rc;
+            float *dxn = WS(oDc);
+            if ((rc = lin_bwd(du_part, WS(a.xn2), key(l, "1.module.attention.query_proj.linear.weight"), key(l, "1.module.attention.query_proj.linear.bias"), M, D, D, dxn))) return rc;
+            if ((rc = lin_bwd(WS(oDe), WS(a.xn2), key(l, "1.module.attention.key_proj.linear.weight"), key(l, "1.module.attention.key_proj.linear.bias"), M, D, D, WS(oDwide2)))) return rc;
+            hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, dxn, WS(oDwide2), 1.0f, MD);
+            if ((rc = lin_bwd(WS(oDa), WS(a.xn2), key(l, "1.module.attention.value_proj.linear.weight"), key(l, "1.module.attention.value_proj.linear.bias"), M, D, D, WS(oDwide2)))) return rc;
+            hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, dxn, WS(oDwide2), 1.0f, MD);
+            // (ln_bwd uses oDwide2 as its product scratch: dxn lives in oDc)
+            ln_bwd(dxn, WS(a.x1), WS(a.mu2), WS(a.rs2), key(l, "1.module.layer_norm.weight"), key(l, "1.module.layer_norm.bias"), dx, 1);
+        }
+        if ((rc = ffn_bwd(l, 0, WS(a.x_in), a.xn1, a.mu1, a.rs1, a.h1, a.a1, dx))) return rc;
+        // dx is now d x_in of block l = d (output of block l-1's LayerNorm): keep it out of the buffers the next iteration overwrites first
+        copy(WS(oDb), dx, MD);
+        dx = WS(oDb);
+    }
+    // ---- frontend
+    dropout(dx, MD, p_in, 1);
+    if ((rc = lin_bwd(dx, WS(oZt), "encoder.conv_subsample.out.0.weight", "encoder.conv_subsample.out.0.bias", M, D, C * F, WS(oZg)))) return rc;
+    {
+        float *dz3 = WS(oZa), *dz2 = WS(oZb);
+        hipLaunchKernelGGL(k_tfc_to_tcf, grid1((size_t)M * F * C), dim3(256), 0, s, WS(oZg), dz3, (size_t)M, F, C, 1);
+        for (int i = snum - 2, idx = 2 + 3 * (snum - 2); i >= 0; --i, idx -= 3) {
+            const size_t rows = (size_t)N * Ts[i + 1] * Fs[i + 1];
+            hipLaunchKernelGGL(k_relu_bwd, grid1(rows * C), dim3(256), 0, s, WS(stg[i].z3), dz3, rows * C);
+            if ((rc = lin_bwd(dz3, WS(stg[i].z2), conv_name(idx + 1, "weight"), conv_name(idx + 1, "bias"), (int)rows, C, C, dz2))) return rc;
+            const float *zin = i == 0 ? WS(oZ1) : WS(stg[i - 1].z3);
+            const int chunks = ceil_div((int)rows, COCR_CV_POS);
+            hipLaunchKernelGGL(k_dw3_bwd_w, dim3(ceil_div(C, 64), chunks), dim3(64), 0, s, dz2, zin, WS(oPart), N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
+            hipLaunchKernelGGL(k_conv_w_final, dim3(ceil_div(C * 10, 256)), dim3(256), 0, s, WS(oPart), chunks, C, Gp(conv_name(idx, "weight")), Gp(conv_name(idx, "bias")));
+            float *dzin = i == 0 ? WS(oZ1g) : dz3;              // (for i > 0 the previous stage's d z3 has the shape of z3[i-1] <= big_rows x C)
+            hipLaunchKernelGGL(k_dw3_bwd_in, grid1((size_t)N * Ts[i] * Fs[i] * C), dim3(256), 0, s, dz2, Pp(conv_name(idx, "weight")), dzin, N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
+        }
+        const size_t n1 = (size_t)N * Ts[0] * Fs[0];
+        hipLaunchKernelGGL(k_relu_bwd, grid1(n1 * C), dim3(256), 0, s, WS(oZ1), WS(oZ1g), n1 * C);
+        const int chunks = ceil_div((int)n1, COCR_CV_POS);
+        hipLaunchKernelGGL(k_conv0_bwd_w, dim3(ceil_div(C, 64), chunks), dim3(64), 0, s, WS(oZ1g), X, WS(oPart), N, H, W, Ts[0], Fs[0], C);
+        hipLaunchKernelGGL(k_conv_w_final, dim3(ceil_div(C * 10, 256)), dim3(256), 0, s, WS(oPart), chunks, C, Gp("encoder.conv_subsample.conv.0.weight"),
+                           Gp("encoder.conv_subsample.conv.0.bias"));
+    }
+    LAUNCH_CHECK();
+    return COCR_OK;
+}

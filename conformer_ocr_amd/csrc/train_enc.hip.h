@@ -1,0 +1,449 @@
+// Training step of the whole network -- the kernels of `RecognitionModel.training_step` (reference model.py:129-152: forward in train
+// mode, CTC criterion, `loss.backward()` through decoder and encoder) that are not matrix products.  fp32 throughout (the reference trains
+// in fp32 unless told otherwise, cli/__init__.py:39-70): correctness-first kernels, one thread / one wave per output with fixed-order
+// reductions (no floating-point atomics: two runs of a step give the same bits).  The matrix products -- forward, input gradient and
+// weight gradient of every Linear / pointwise conv -- run on the exact-fp32 MFMA GEMM of gemm.hip.h through explicit transposes
+// (train_api.hip.h).  Train-mode semantics: BatchNorm1d with batch statistics over ALL (line, frame) positions of the padded batch
+// (convolution.py:141; no masking anywhere) and running-statistics update (momentum 0.1, unbiased variance); dropout at the
+// reference's six sites (convolution.py:144,225; feed_forward.py:49,51; attention.py:98,151) from a counter-based generator, so
+// the backward regenerates the masks instead of storing them.
+#pragma once
+#include "common.hip.h"
+
+// ---- dropout: keep(seed, site, index) -------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((unsigned long long)site << 48);      // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
+// x <- keep ? x / (1 - p) : 0 (forward on activations, backward on their gradients: the same mask)
+__global__ static void k_dropout(float *x, size_t n, float p, unsigned long long seed, unsigned site) {
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = drop_keep(seed, site, i, p) ? x[i] * sc : 0.f;
+}
+
+// ---- small elementwise helpers ------------------------------------------------------------------------------------------------------
+__global__ static void k_axpy(float *y, const float *x, float alpha, size_t n) {          // y += alpha x
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaf(alpha, x[i], y[i]);
+}
+__global__ static void k_add3(float *y, const float *a, const float *b, float alpha, size_t n) {      // y = a + alpha b
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaf(alpha, b[i], a[i]);
+}
+__global__ static void k_u8_to_f32(const uint8_t *in, float *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i] * (1.0f / 255.0f);
+}
+// out[c * ldo + r] = in[r * C + c]   (ldo >= R; the tail r in [R, ldo) must have been zeroed by the caller)
+__global__ static void k_transpose(const float *__restrict__ in, float *__restrict__ out, int R, int C, int ldo) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = in[(size_t)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) out[(size_t)(c0 + j) * ldo + r0 + tx] = tile[tx][j];
+}
+// out (M, ldo) <- in (M, C), columns C..ldo-1 zero
+__global__ static void k_pad_cols(const float *__restrict__ in, float *__restrict__ out, int M, int C, int ldo) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * ldo; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ldo);
+        out[i] = c < C ? in[(i / ldo) * C + c] : 0.f;
+    }
+}
+// column sums of a (M, N) matrix, optionally of the elementwise product a .* b: part[chunk][n] over 256-row chunks, then out[n] (+)= sum of chunks
+#define COCR_CS_ROWS 256
+__global__ static void k_colsum_partial(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
+    if (n >= N) return;
+    const int r0 = chunk * COCR_CS_ROWS, r1 = min(M, r0 + COCR_CS_ROWS);
+    float s = 0.f;
+    if (b) for (int r = r0; r < r1; ++r) s = fmaf(a[(size_t)r * N + n], b[(size_t)r * N + n], s);
+    else for (int r = r0; r < r1; ++r) s += a[(size_t)r * N + n];
+    part[(size_t)chunk * N + n] = s;
+}
+__global__ static void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int chunks, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = accumulate ? out[n] : 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * N + n];
+    out[n] = s;
+}
+
+// ---- LayerNorm (eps 1e-5): one wave per row -----------------------------------------------------------------------------------------------
+__global__ static void k_ln_fwd(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b, float *__restrict__ y,
+                                float *__restrict__ mean, float *__restrict__ rstd, int M, int D) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += xr[d];
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int d = lane; d < D; d += 64) { const float t = xr[d] - mu; q = fmaf(t, t, q); }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    for (int d = lane; d < D; d += 64) y[(size_t)row * D + d] = fmaf((xr[d] - mu) * rs, g[d], b[d]);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+// dx (+)= rstd (dy g - mean_d(dy g) - xhat mean_d(dy g xhat));  dyxhat = dy .* xhat (for d gamma = column sum; d beta = column sum of dy)
+__global__ static void k_ln_bwd(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                const float *__restrict__ g, float *__restrict__ dx, float *__restrict__ dyxhat, int M, int D, int accumulate) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float mu = mean[row], rs = rstd[row];
+    const float *xr = x + (size_t)row * D, *dr = dy + (size_t)row * D;
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float xh = (xr[d] - mu) * rs, dg = dr[d] * g[d];
+        s1 += dg;
+        s2 = fmaf(dg, xh, s2);
+    }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+    for (int d = lane; d < D; d += 64) {
+        const float xh = (xr[d] - mu) * rs, v = rs * (dr[d] * g[d] - c1 - xh * c2);
+        const size_t o = (size_t)row * D + d;
+        dyxhat[o] = dr[d] * xh;
+        dx[o] = accumulate ? dx[o] + v : v;
+    }
+}
+
+// ---- activations -----------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__global__ static void k_silu_fwd(const float *__restrict__ h, float *__restrict__ a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = h[i] * sigm(h[i]);
+}
+__global__ static void k_silu_bwd(const float *__restrict__ h, float *__restrict__ d, size_t n) {      // d <- d * silu'(h)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = sigm(h[i]);
+        d[i] *= s * fmaf(h[i], 1.0f - s, 1.0f);
+    }
+}
+// GLU over channels (convolution.py:139, dim=1 of (B, 2D, T)): g[m, c] = a[m, c] * sigmoid(a[m, D + c])
+__global__ static void k_glu_fwd(const float *__restrict__ a, float *__restrict__ g, int M, int D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * D; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / D, c = i - m * D;
+        g[i] = a[m * 2 * D + c] * sigm(a[m * 2 * D + D + c]);
+    }
+}
+__global__ static void k_glu_bwd(const float *__restrict__ a, const float *__restrict__ dg, float *__restrict__ da, int M, int D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * D; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / D, c = i - m * D;
+        const float v = a[m * 2 * D + c], s = sigm(a[m * 2 * D + D + c]);
+        da[m * 2 * D + c] = dg[i] * s;
+        da[m * 2 * D + D + c] = dg[i] * v * s * (1.0f - s);
+    }
+}
+__global__ static void k_relu_bwd(const float *__restrict__ y, float *__restrict__ d, size_t n) {       // d <- y > 0 ? d : 0
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = y[i] > 0.f ? d[i] : 0.f;
+}
+__global__ static void k_relu(float *y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaxf(y[i], 0.f);
+}
+
+// ---- relative-position attention (attention.py:72-113), train mode --------------------------------------------------------------------------------
+// q, k, v (M, D) with head h in columns [h dh, (h+1) dh); P (2T-1, D): row r <-> relative position (T-1) - r, so score(i, j) uses row T-1-(i-j);
+// u, vb (D) = u_bias / v_bias flattened (h, dh).  attn (N, h, T, T) is stored UNdropped; the dropout mask of the attention weights is
+// regenerated from (seed, site, element index).
+// forward: one wave per (line, head, query)
+__global__ static void k_attn_fwd(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ P,
+                                  const float *__restrict__ u, const float *__restrict__ vb, float *__restrict__ attn, float *__restrict__ ctx,
+                                  long long total, int T, int H, int dh, float scale, float p, unsigned long long seed, unsigned site) {
+    extern __shared__ float sm[];                      // per wave: qu[dh], qv[dh]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const long long row = (long long)blockIdx.x * wpb + wave;       // (b * H + h) * T + i
+    if (row >= total) return;
+    const int D = H * dh;
+    const int i = (int)(row % T), bh = (int)(row / T), h = bh % H, b = bh / H;
+    float *qu = sm + wave * 2 * dh, *qv = qu + dh;
+    const float *qr = q + ((size_t)b * T + i) * D + h * dh;
+    for (int d = lane; d < dh; d += 64) { qu[d] = qr[d] + u[h * dh + d]; qv[d] = qr[d] + vb[h * dh + d]; }
+    __builtin_amdgcn_wave_barrier();
+    float *ar = attn + (size_t)row * T;
+    float mx = -INFINITY;
+    for (int j = lane; j < T; j += 64) {
+        const float *kr = k + ((size_t)b * T + j) * D + h * dh, *pr = P + (size_t)(T - 1 - (i - j)) * D + h * dh;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s = fmaf(qu[d], kr[d], fmaf(qv[d], pr[d], s));
+        s *= scale;
+        ar[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) { const float e = expf(ar[j] - mx); ar[j] = e; sum += e; }
+    const float inv = 1.0f / wave_sum(sum);
+    for (int j = lane; j < T; j += 64) ar[j] *= inv;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int d = lane; d < dh; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) {
+            float a = ar[j];
+            if (p > 0.f) a = drop_keep(seed, site, (unsigned long long)row * T + j, p) ? a * sc : 0.f;
+            acc = fmaf(a, v[((size_t)b * T + j) * D + h * dh + d], acc);
+        }
+        ctx[((size_t)b * T + i) * D + h * dh + d] = acc;
+    }
+}
+// backward, rows: one wave per (line, head, query): ds (overwrites `dsb` row), du_part[i] = sum_j ds k_j, dvb_part[i] = sum_j ds P_rel  (dq = their sum)
+__global__ static void k_attn_bwd_rows(const float *__restrict__ dctx, const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ P,
+                                       const float *__restrict__ attn, float *__restrict__ dsb, float *__restrict__ du_part, float *__restrict__ dvb_part,
+                                       long long total, int T, int H, int dh, float scale, float p, unsigned long long seed, unsigned site) {
+    extern __shared__ float sm[];                      // per wave: dctx row [dh]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const long long row = (long long)blockIdx.x * wpb + wave;
+    if (row >= total) return;
+    const int D = H * dh, i = (int)(row % T), bh = (int)(row / T), h = bh % H, b = bh / H;
+    float *dc = sm + wave * dh;
+    for (int d = lane; d < dh; d += 64) dc[d] = dctx[((size_t)b * T + i) * D + h * dh + d];
+    __builtin_amdgcn_wave_barrier();
+    const float *ar = attn + (size_t)row * T;
+    float *dr = dsb + (size_t)row * T;
+    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    float delta = 0.f;
+    for (int j = lane; j < T; j += 64) {
+        const float *vr = v + ((size_t)b * T + j) * D + h * dh;
+        float da = 0.f;
+        for (int d = 0; d < dh; ++d) da = fmaf(dc[d], vr[d], da);
+        if (p > 0.f) da = drop_keep(seed, site, (unsigned long long)row * T + j, p) ? da * sc : 0.f;      // d loss / d (undropped attention weight)
+        dr[j] = da;
+        delta = fmaf(ar[j], da, delta);
+    }
+    delta = wave_sum(delta);
+    for (int j = lane; j < T; j += 64) dr[j] = ar[j] * (dr[j] - delta) * scale;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int d = lane; d < dh; d += 64) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const float ds = dr[j];
+            a1 = fmaf(ds, k[((size_t)b * T + j) * D + h * dh + d], a1);
+            a2 = fmaf(ds, P[(size_t)(T - 1 - (i - j)) * D + h * dh + d], a2);
+        }
+        du_part[((size_t)b * T + i) * D + h * dh + d] = a1;
+        dvb_part[((size_t)b * T + i) * D + h * dh + d] = a2;
+    }
+}
+// backward, columns: one wave per (line, head, key j): dk_j = sum_i ds_ij (q_i + u), dv_j = sum_i attn_dropped_ij dctx_i
+__global__ static void k_attn_bwd_cols(const float *__restrict__ dctx, const float *__restrict__ q, const float *__restrict__ u, const float *__restrict__ attn,
+                                       const float *__restrict__ dsb, float *__restrict__ dk, float *__restrict__ dv,
+                                       long long total, int T, int H, int dh, float p, unsigned long long seed, unsigned site) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const long long col = (long long)blockIdx.x * wpb + wave;       // (b * H + h) * T + j
+    if (col >= total) return;
+    const int D = H * dh, j = (int)(col % T), bh = (int)(col / T), h = bh % H, b = bh / H;
+    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int d = lane; d < dh; d += 64) {
+        float a1 = 0.f, a2 = 0.f;
+        const float ud = u[h * dh + d];
+        for (int i = 0; i < T; ++i) {
+            const size_t e = ((size_t)bh * T + i) * T + j;
+            a1 = fmaf(dsb[e], q[((size_t)b * T + i) * D + h * dh + d] + ud, a1);
+            float a = attn[e];
+            if (p > 0.f) a = drop_keep(seed, site, e, p) ? a * sc : 0.f;
+            a2 = fmaf(a, dctx[((size_t)b * T + i) * D + h * dh + d], a2);
+        }
+        dk[((size_t)b * T + j) * D + h * dh + d] = a1;
+        dv[((size_t)b * T + j) * D + h * dh + d] = a2;
+    }
+}
+// backward, positional table: one wave per (row r, head): dP[r, h, :] = sum over lines and the diagonal i - j = T-1-r of ds_ij (q_i + vb)
+__global__ static void k_attn_bwd_pos(const float *__restrict__ q, const float *__restrict__ vb, const float *__restrict__ dsb, float *__restrict__ dP,
+                                      int N, int T, int H, int dh) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int id = blockIdx.x * wpb + wave;             // r * H + h
+    if (id >= (2 * T - 1) * H) return;
+    const int D = H * dh, r = id / H, h = id - r * H, off = T - 1 - r;      // i - j = off
+    const int i0 = max(0, off), i1 = min(T, T + off);
+    for (int d = lane; d < dh; d += 64) {
+        float acc = 0.f;
+        const float vd = vb[h * dh + d];
+        for (int b = 0; b < N; ++b)
+            for (int i = i0; i < i1; ++i)
+                acc = fmaf(dsb[(((size_t)b * H + h) * T + i) * T + (i - off)], q[((size_t)b * T + i) * D + h * dh + d] + vd, acc);
+        dP[(size_t)r * D + h * dh + d] = acc;
+    }
+}
+
+// ---- conv module: depthwise conv along time (convolution.py:140; cross-correlation, zero padding at the ends of the PADDED batch rows) --------
+__global__ static void k_dw1d_fwd(const float *__restrict__ g, const float *__restrict__ w, float *__restrict__ out, int N, int T, int D, int K) {
+    const int pad = (K - 1) / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * T * D; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D), t = (int)((i / D) % T);
+        const size_t base = i - (size_t)t * D;
+        float acc = 0.f;
+        for (int tau = 0; tau < K; ++tau) {
+            const int tt = t + tau - pad;
+            if (tt >= 0 && tt < T) acc = fmaf(w[c * K + tau], g[base + (size_t)tt * D], acc);
+        }
+        out[i] = acc;
+    }
+}
+__global__ static void k_dw1d_bwd_in(const float *__restrict__ dout, const float *__restrict__ w, float *__restrict__ dg, int N, int T, int D, int K) {
+    const int pad = (K - 1) / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * T * D; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D), t = (int)((i / D) % T);
+        const size_t base = i - (size_t)t * D;
+        float acc = 0.f;
+        for (int tau = 0; tau < K; ++tau) {
+            const int to = t - tau + pad;               // output frame whose tap tau read input frame t
+            if (to >= 0 && to < T) acc = fmaf(w[c * K + tau], dout[base + (size_t)to * D], acc);
+        }
+        dg[i] = acc;
+    }
+}
+// dw[c, tau] = sum over lines and frames of dout[b, t, c] g[b, t + tau - pad, c]: thread = (c, tau), rows in order
+__global__ static void k_dw1d_bwd_w(const float *__restrict__ dout, const float *__restrict__ g, float *__restrict__ dw, int N, int T, int D, int K) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, tau = blockIdx.y, pad = (K - 1) / 2;
+    if (c >= D) return;
+    float acc = 0.f;
+    for (int b = 0; b < N; ++b)
+        for (int t = max(0, pad - tau); t < min(T, T + pad - tau); ++t)
+            acc = fmaf(dout[((size_t)b * T + t) * D + c], g[((size_t)b * T + t + tau - pad) * D + c], acc);
+    dw[c * K + tau] = acc;
+}
+
+// ---- BatchNorm1d, train mode (convolution.py:141) -------------------------------------------------------------------------------------------------
+// from column sums of x and x^2 over the M positions: batch mean, 1/sqrt(biased var + eps); running statistics (momentum 0.1, unbiased variance)
+__global__ static void k_bn_finalize(const float *__restrict__ sum, const float *__restrict__ sumsq, int M, int D, float *__restrict__ mean, float *__restrict__ rstd,
+                                     float *__restrict__ running_mean, float *__restrict__ running_var, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    const float mu = sum[c] / (float)M, var = fmaxf(sumsq[c] / (float)M - mu * mu, 0.f);
+    mean[c] = mu;
+    rstd[c] = 1.0f / sqrtf(var + 1e-5f);
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * var * ((float)M / (float)max(M - 1, 1));
+}
+__global__ static void k_bn_apply(const float *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ g,
+                                  const float *__restrict__ b, float *__restrict__ xhat, float *__restrict__ y, int M, int D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * D; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const float xh = (x[i] - mean[c]) * rstd[c];
+        xhat[i] = xh;
+        y[i] = fmaf(xh, g[c], b[c]);
+    }
+}
+// dx = g rstd / M (M dy - sum dy - xhat sum(dy xhat))
+__global__ static void k_bn_bwd(const float *__restrict__ dy, const float *__restrict__ xhat, const float *__restrict__ g, const float *__restrict__ rstd,
+                                const float *__restrict__ sum_dy, const float *__restrict__ sum_dyxh, float *__restrict__ dx, int M, int D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * D; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        dx[i] = g[c] * rstd[c] * (dy[i] - (sum_dy[c] + xhat[i] * sum_dyxh[c]) / (float)M);
+    }
+}
+
+// ---- frontend convolutions (convolution.py:192-213), channel-last activations (n, t, f, c) --------------------------------------------------------
+// conv.0: Z1[n, t1, f1, c] = relu(b0[c] + sum_{dt,df} w0[c, dt, df] X[n, 2 f1 + df - 1, 2 t1 + dt - 1])    (X (N, H, W); zero outside)
+__global__ static void k_conv0_fwd(const float *__restrict__ X, const float *__restrict__ w0, const float *__restrict__ b0, float *__restrict__ Z1,
+                                   int N, int H, int W, int T1, int F1, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * T1 * F1 * C; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), f = (int)((i / C) % F1), t = (int)((i / ((size_t)C * F1)) % T1), n = (int)(i / ((size_t)C * F1 * T1));
+        float acc = b0[c];
+        for (int dt = 0; dt < 3; ++dt)
+            for (int df = 0; df < 3; ++df) {
+                const int col = 2 * t + dt - 1, row = 2 * f + df - 1;
+                if (col >= 0 && col < W && row >= 0 && row < H) acc = fmaf(w0[c * 9 + dt * 3 + df], X[((size_t)n * H + row) * W + col], acc);
+            }
+        Z1[i] = fmaxf(acc, 0.f);
+    }
+}
+// d w0[c, tap] and d b0[c] partial sums over chunks of positions (dZ1 already masked by the ReLU): thread = c, block.y = chunk
+#define COCR_CV_POS 512
+__global__ static void k_conv0_bwd_w(const float *__restrict__ dZ1, const float *__restrict__ X, float *__restrict__ part, int N, int H, int W, int T1, int F1, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
+    if (c >= C) return;
+    const size_t npos = (size_t)N * T1 * F1, p0 = (size_t)chunk * COCR_CV_POS, p1 = min(npos, p0 + COCR_CV_POS);
+    float acc[10];
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    for (size_t pos = p0; pos < p1; ++pos) {
+        const int f = (int)(pos % F1), t = (int)((pos / F1) % T1), n = (int)(pos / ((size_t)F1 * T1));
+        const float d = dZ1[pos * C + c];
+        acc[9] += d;
+        for (int dt = 0; dt < 3; ++dt)
+            for (int df = 0; df < 3; ++df) {
+                const int col = 2 * t + dt - 1, row = 2 * f + df - 1;
+                if (col >= 0 && col < W && row >= 0 && row < H) acc[dt * 3 + df] = fmaf(d, X[((size_t)n * H + row) * W + col], acc[dt * 3 + df]);
+            }
+    }
+    for (int k = 0; k < 10; ++k) part[((size_t)chunk * 10 + k) * C + c] = acc[k];       // [chunk][tap 0..8, bias][c]
+}
+// depthwise 3x3 stride 2: Zo[n, t, f, c] = b[c] + sum w[c, dt, df] Zi[n, 2 t + dt - 1, 2 f + df - 1, c]
+__global__ static void k_dw3_fwd(const float *__restrict__ Zi, const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ Zo,
+                                 int N, int Ti, int Fi, int To, int Fo, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * To * Fo * C; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), f = (int)((i / C) % Fo), t = (int)((i / ((size_t)C * Fo)) % To), n = (int)(i / ((size_t)C * Fo * To));
+        float acc = b[c];
+        for (int dt = 0; dt < 3; ++dt)
+            for (int df = 0; df < 3; ++df) {
+                const int ti = 2 * t + dt - 1, fi = 2 * f + df - 1;
+                if (ti >= 0 && ti < Ti && fi >= 0 && fi < Fi) acc = fmaf(w[c * 9 + dt * 3 + df], Zi[(((size_t)n * Ti + ti) * Fi + fi) * C + c], acc);
+            }
+        Zo[i] = acc;
+    }
+}
+__global__ static void k_dw3_bwd_in(const float *__restrict__ dZo, const float *__restrict__ w, float *__restrict__ dZi, int N, int Ti, int Fi, int To, int Fo, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * Ti * Fi * C; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), fi = (int)((i / C) % Fi), ti = (int)((i / ((size_t)C * Fi)) % Ti), n = (int)(i / ((size_t)C * Fi * Ti));
+        float acc = 0.f;
+        for (int dt = 0; dt < 3; ++dt) {
+            const int t2 = ti + 1 - dt;                  // 2 t + dt - 1 = ti
+            if (t2 < 0 || (t2 & 1) || (t2 >> 1) >= To) continue;
+            for (int df = 0; df < 3; ++df) {
+                const int f2 = fi + 1 - df;
+                if (f2 < 0 || (f2 & 1) || (f2 >> 1) >= Fo) continue;
+                acc = fmaf(w[c * 9 + dt * 3 + df], dZo[(((size_t)n * To + (t2 >> 1)) * Fo + (f2 >> 1)) * C + c], acc);
+            }
+        }
+        dZi[i] = acc;
+    }
+}
+__global__ static void k_dw3_bwd_w(const float *__restrict__ dZo, const float *__restrict__ Zi, float *__restrict__ part, int N, int Ti, int Fi, int To, int Fo, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
+    if (c >= C) return;
+    const size_t npos = (size_t)N * To * Fo, p0 = (size_t)chunk * COCR_CV_POS, p1 = min(npos, p0 + COCR_CV_POS);
+    float acc[10];
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    for (size_t pos = p0; pos < p1; ++pos) {
+        const int f = (int)(pos % Fo), t = (int)((pos / Fo) % To), n = (int)(pos / ((size_t)Fo * To));
+        const float d = dZo[pos * C + c];
+        acc[9] += d;
+        for (int dt = 0; dt < 3; ++dt)
+            for (int df = 0; df < 3; ++df) {
+                const int ti = 2 * t + dt - 1, fi = 2 * f + df - 1;
+                if (ti >= 0 && ti < Ti && fi >= 0 && fi < Fi) acc[dt * 3 + df] = fmaf(d, Zi[(((size_t)n * Ti + ti) * Fi + fi) * C + c], acc[dt * 3 + df]);
+            }
+    }
+    for (int k = 0; k < 10; ++k) part[((size_t)chunk * 10 + k) * C + c] = acc[k];
+}
+// partials [chunk][10][C] -> dw[c][9] and db[c]
+__global__ static void k_conv_w_final(const float *__restrict__ part, int chunks, int C, float *__restrict__ dw, float *__restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // c * 10 + k
+    if (i >= C * 10) return;
+    const int c = i / 10, k = i - c * 10;
+    float s = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) s += part[((size_t)ch * 10 + k) * C + c];
+    if (k < 9) dw[c * 9 + k] = s; else db[c] = s;
+}
+// (n, t, c, f) <-> (n, t, f, c): the reference flattens the frontend output channel-major (convolution.py:235-236: feature index c F + f)
+__global__ static void k_tfc_to_tcf(const float *__restrict__ in, float *__restrict__ out, size_t NT, int F, int C, int reverse) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NT * F * C; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), f = (int)((i / C) % F);
+        const size_t nt = i / ((size_t)C * F), o = (nt * C + c) * F + f;
+        if (reverse) out[i] = in[o]; else out[o] = in[i];
+    }
+}
+
+// ---- torch.optim.AdamW (model.py:283-284) on a flat parameter vector ------------------------------------------------------------------------------
+__global__ static void k_adamw_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, size_t n, float lr,
+                                    float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float w = p[i] * (1.0f - lr * wd);
+        const float gi = g[i], mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w -= lr / bc1 * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+        p[i] = w;
+    }
+}

@@ -273,6 +273,60 @@ class HipRecognizer:
             out[name] = a
         return out
 
+    # ---- training step of the whole network (include/cocr.h: cocr_train_*) ------------------------------
+    def train_begin(self) -> None:
+        """fp32 master copy of the loaded state (`load_state`) on the device, zeroed AdamW moments."""
+        _lib.check(self.lib.cocr_train_begin(self._h))
+
+    def train_step(self, lines: torch.Tensor, lens, targets, label_lens, dropout=(0.0, 0.0, 0.0, 0.0), seed: int = 0) -> float:
+        """`RecognitionModel.training_step` without the optimizer (reference model.py:129-152): train-mode forward, summed CTC loss,
+        backward through decoder and encoder.  lines (N,H,W) float32 / uint8 on this device; lens pixel widths; targets the
+        concatenated labels, label_lens their per-line counts; dropout = (input, feed_forward, attention, conv) probabilities.
+        Returns the loss; the gradients stay on the device (`train_grad`, `train_adamw`)."""
+        if lines.device != self.device or lines.dim() != 3:
+            raise ValueError('expected a (N,H,W) batch on the model device')
+        ldt = _lib.U8 if lines.dtype == torch.uint8 else _lib.F32
+        lines = (lines if ldt == _lib.U8 else lines.float()).contiguous()
+        N, H, W = lines.shape
+        i32 = C.POINTER(C.c_int32)
+        il = np.ascontiguousarray(np.asarray(lens, dtype=np.int32).reshape(-1))
+        tg = np.ascontiguousarray(np.asarray(targets, dtype=np.int32).reshape(-1))
+        tl = np.ascontiguousarray(np.asarray(label_lens, dtype=np.int32).reshape(-1))
+        if il.shape[0] != N or tl.shape[0] != N or int(tl.sum()) != tg.shape[0]:
+            raise ValueError('lens / label_lens need one entry per line and targets sum(label_lens) labels')
+        dp = (C.c_float * 4)(*[float(x) for x in dropout])
+        loss = C.c_float()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_train_step(self._h, C.c_void_p(lines.data_ptr()), ldt, N, H, W, il.ctypes.data_as(i32),
+                                                tg.ctypes.data_as(i32) if tg.shape[0] else None, tl.ctypes.data_as(i32), dp, C.c_uint64(int(seed)),
+                                                C.byref(loss), _stream_ptr(self.device)))
+        return float(loss.value)
+
+    def _train_get(self, name: str, kind: int) -> np.ndarray:
+        from .spec import model_state_spec
+        shape = model_state_spec(self.hp)[name][0]
+        a = np.empty(shape, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_train_get(self._h, name.encode(), kind, a.ctypes.data_as(C.c_void_p), a.size, _stream_ptr(self.device)))
+        return a
+
+    def train_grad(self, name: str) -> np.ndarray:
+        """d loss / d `name` of the last `train_step` (reference state-dict name, e.g. 'encoder.layers.0.sequential.1.module.attention.u_bias')."""
+        return self._train_get(name, 1)
+
+    def train_value(self, name: str) -> np.ndarray:
+        """Current value of a parameter or buffer (BatchNorm running statistics) of the training state."""
+        return self._train_get(name, 0)
+
+    def train_adamw(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2) -> None:
+        """One torch.optim.AdamW step on all parameters with the gradients of the last `train_step` (defaults are torch's)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cocr_train_adamw(self._h, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _stream_ptr(self.device)))
+
+    def train_end(self) -> None:
+        """Trained values back into the model's state; `finalize()` again to serve them."""
+        _lib.check(self.lib.cocr_train_end(self._h))
+
     # ---- line pre-processing (include/cocr.h: cocr_preproc_lines) --------------------------------------
     def preprocess(self, lines: Sequence[np.ndarray], height: Optional[int] = None, pad: int = 16, width: int = 0,
                    bucket_edge: int = 0) -> Tuple[torch.Tensor, np.ndarray]:

@@ -201,6 +201,22 @@ int cocr_debug_tap(cocr_model *m, const char *name, float *host_out, int64_t max
 int cocr_profile(cocr_model *m, int on);
 int cocr_profile_read(cocr_model *m, char *names, size_t names_len, double *ms, int64_t *launches, int max_entries);
 
+/* ---- Training step of the whole network: RecognitionModel.training_step (model.py:129-152) + torch.optim.AdamW (model.py:283-284).
+ * fp32.  cocr_train_begin copies every parameter / buffer given through cocr_set_tensor to the device (AdamW state zeroed);
+ * cocr_train_step runs the TRAIN-mode forward (BatchNorm1d batch statistics over all positions of the padded batch + running-statistics
+ * update, dropout at the reference's six sites with probabilities dropout_p = {input, feed_forward, attention, conv}, masks from
+ * (seed, site, index)), the criterion nn.CTCLoss(reduction='sum', zero_infinity=True) on log_softmax(probits), and the backward through
+ * decoder and encoder: afterwards cocr_train_get(name, kind = 1) returns d loss / d parameter for every reference state-dict name
+ * (kind = 0: the current value of a parameter / buffer).  lines as for cocr_forward; in_lens, targets (concatenated labels),
+ * label_lens HOST int32; *loss_out HOST.  cocr_train_adamw applies one AdamW step to all parameters; cocr_train_end copies the trained
+ * values back into the model's state (call cocr_finalize again to serve them) and frees the training state. */
+int cocr_train_begin(cocr_model *m);
+int cocr_train_step(cocr_model *m, const void *lines, int line_dtype, int N, int H, int W, const int32_t *in_lens, const int32_t *targets,
+                    const int32_t *label_lens, const float *dropout_p, uint64_t seed, float *loss_out, void *stream);
+int cocr_train_get(cocr_model *m, const char *name, int kind, float *host_out, int64_t n_elems, void *stream);
+int cocr_train_adamw(cocr_model *m, float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
+int cocr_train_end(cocr_model *m);
+
 #ifdef __cplusplus
 }
 #endif
