@@ -83,6 +83,16 @@ extern "C" int cocr_train_get(cocr_model *m, const char *name, int kind, float *
     return COCR_OK;
 }
 
+// the flat device gradient vector (all parameters, the order of cocr_train_begin): what a data-parallel job all-reduces between
+// cocr_train_step and cocr_train_adamw
+extern "C" int cocr_train_grad_buffer(cocr_model *m, void **device_ptr, size_t *n_floats) {
+    if (!m || !device_ptr || !n_floats) return fail(COCR_EINVAL, "null argument");
+    if (!m->train) return fail(COCR_ESTATE, "cocr_train_begin has not been called");
+    *device_ptr = m->train->G;
+    *n_floats = m->train->nparam;
+    return COCR_OK;
+}
+
 extern "C" int cocr_train_end(cocr_model *m) {
     if (!m) return fail(COCR_EINVAL, "null argument");
     TrainState *t = m->train;

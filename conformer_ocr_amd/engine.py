@@ -323,6 +323,17 @@ class HipRecognizer:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cocr_train_adamw(self._h, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _stream_ptr(self.device)))
 
+    def train_grad_buffer(self) -> torch.Tensor:
+        """The flat gradient vector of all parameters as a float32 torch view of library-owned memory (for an all-reduce)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self.lib.cocr_train_grad_buffer(self._h, C.byref(p), C.byref(n)))
+
+        class _Mem:
+            def __init__(s, owner):
+                s.owner = owner
+                s.__cuda_array_interface__ = {'shape': (n.value,), 'typestr': '<f4', 'data': (p.value, False), 'version': 2}
+        return torch.as_tensor(_Mem(self), device=self.device)
+
     def train_end(self) -> None:
         """Trained values back into the model's state; `finalize()` again to serve them."""
         _lib.check(self.lib.cocr_train_end(self._h))

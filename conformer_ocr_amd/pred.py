@@ -105,6 +105,8 @@ class PytorchRecognitionModel(nn.Module):
         self.channels = 1
         self.width = 0
         self.compute_dtype = kwargs.get('compute_dtype', 'bf16')
+        # the reference's four dropout probabilities: identity at inference, used by conformer_ocr_amd.train.Trainer
+        self.dropout_p = (float(input_dropout_p), float(feed_forward_dropout_p), float(attention_dropout_p), float(conv_dropout_p))
         # rows per workgroup of the row-chain kernels (include/cocr.h cocr_set_chain_rows).  This class is called one batch at a time
         # (the reference's loop, cli/test.py:185-199): 48-row blocks give every CU a workgroup at 32 x 300 frames and the shortest
         # forward; a caller that keeps several batches in flight on its own streams (bench.py) passes chain_rows=0.

@@ -216,6 +216,8 @@ int cocr_train_step(cocr_model *m, const void *lines, int line_dtype, int N, int
 int cocr_train_get(cocr_model *m, const char *name, int kind, float *host_out, int64_t n_elems, void *stream);
 int cocr_train_adamw(cocr_model *m, float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
 int cocr_train_end(cocr_model *m);
+/* The flat device gradient vector (float32, all parameters): a data-parallel job all-reduces it between cocr_train_step and cocr_train_adamw. */
+int cocr_train_grad_buffer(cocr_model *m, void **device_ptr, size_t *n_floats);
 
 #ifdef __cplusplus
 }

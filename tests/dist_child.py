@@ -44,6 +44,22 @@ def main():
             la, _ = a.forward(x, lens)
             torch.cuda.synchronize()
             out[dtype]['bit_equal_to_direct_finalize'] = bool(torch.equal(la, lb))
+    # one data-parallel training step: the flat gradient vector is averaged over the ranks by one all-reduce
+    from conformer_ocr_amd.codec import ascii_codec
+    from conformer_ocr_amd.pred import PytorchRecognitionModel
+    from conformer_ocr_amd.train import Trainer
+    hpt = synth.hparams('tiny')
+    st = synth.make_state_dict(hpt, seed=9, decoder_gain=1.0)
+    net = PytorchRecognitionModel(**hpt.as_dict(), input_dropout_p=0.0, feed_forward_dropout_p=0.0, attention_dropout_p=0.0, conv_dropout_p=0.0,
+                                  codec=ascii_codec(hpt.num_classes), compute_dtype='fp32')
+    net.nn.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
+    net = net.to(dev).eval()
+    im, ln = synth.make_lines(2, hpt.height, 64, seed=9 + rank, widths=[64, 40])
+    batch = {'image': torch.from_numpy(im), 'seq_lens': torch.from_numpy(ln), 'target': torch.tensor([1, 2, 3]), 'target_lens': torch.tensor([2, 1])}
+    tr = Trainer(net, lr=1e-3, distributed=True)
+    l0 = tr.training_step(batch)
+    l1 = tr.training_step(batch)
+    out['train'] = {'loss0': l0, 'loss1': l1, 'grad_floats': int(tr.engine.train_grad_buffer().numel())}
     out['shard'] = shard_batches(5, rank, world)
     dist.barrier()
     dist.destroy_process_group()

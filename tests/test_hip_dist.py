@@ -33,5 +33,6 @@ def test_nccl_broadcast_start_up_in_a_fresh_process():
     for dtype in ('bf16', 'fp32'):
         o = out[dtype]
         assert o['finite'] and o['same_on_all_ranks'] and o['bit_equal_to_direct_finalize'], o
+    assert out['train']['loss1'] < out['train']['loss0'] and out['train']['grad_floats'] > 10000      # all-reduced flat gradient, AdamW
     # the blob carries weights only: the positional tables (9999 x D per block) are derived per device
     assert out['bf16']['blob_bytes'] < 12e6, out['bf16']

@@ -139,7 +139,7 @@ def oracle_train_grads(hp, state, image, lens, targets, dtype=torch.float64):
     loss = torch.nn.functional.ctc_loss(torch.nn.functional.log_softmax(probits, -1).transpose(0, 1), target, ol.long(), tl,
                                         reduction='sum', zero_infinity=True)                 # model.py:119,136-142
     loss.backward()
-    return float(loss), probits.detach().numpy(), {k: v.grad.numpy() for k, v in params.items()}, o.bn_batch_stats
+    return float(loss.detach()), probits.detach().numpy(), {k: v.grad.numpy() for k, v in params.items()}, o.bn_batch_stats
 
 
 def test_oracle_train_mode_matches_the_reference_training_step():
