@@ -139,7 +139,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     // ---- shapes of the frontend stages
     std::vector<int> Ts(snum), Fs(snum);
     { int tt = W, f = H; for (int i = 0; i < snum; ++i) { tt = out_len1(tt); f = out_len1(f); Ts[i] = tt; Fs[i] = f; } }
-    const int T = Ts.back(), F = Fs.back(), M = N * T, Mp = round_up(M, 32), R = 2 * T - 1, Rp = round_up(R, 32);
+    const int T = Ts.back(), F = Fs.back(), M = N * T, Mp = round_up(M, 1024), R = 2 * T - 1, Rp = round_up(R, 1024);
     const int nclp = round_up(ncls, 4);
     std::vector<int32_t> out_lens(N);
     for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
@@ -172,7 +172,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     // backward scratch
     size_t big_rows = (size_t)M;
     for (int i = 0; i + 1 < snum; ++i) big_rows = std::max(big_rows, (size_t)N * Ts[i + 1] * Fs[i + 1]);
-    const size_t big_rows_p = (big_rows + 31) / 32 * 32;
+    const size_t big_rows_p = (big_rows + 1023) / 1024 * 1024;
     const int wide = std::max(std::max(ff, 3 * D), std::max(C * F, std::max(2 * D, nclp)));
     const size_t tr_floats = std::max((size_t)wide * Mp, big_rows_p * (size_t)C);
     const size_t oTA = rsv(tr_floats), oTB = rsv(tr_floats), oTW = rsv((size_t)std::max(std::max((size_t)ff * D, (size_t)C * F * D), (size_t)std::max(C * C, D * nclp)) + 1024);
@@ -182,6 +182,12 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     const size_t part_floats = std::max((size_t)ceil_div((int)std::min<size_t>(big_rows, 1u << 30), COCR_CS_ROWS) * (size_t)std::max(wide, C * 10),
                                         (size_t)ceil_div((int)std::min<size_t>((size_t)N * Ts[0] * Fs[0], 1u << 30), COCR_CV_POS) * 10 * (size_t)C);
     const size_t oPart = rsv(part_floats + 4096), oVec = rsv(4 * (size_t)std::max(D, C) + 64);
+    // weight gradients are tall-K products (K = rows): split-K partial sums [splits][out x in]
+    auto wg_splits = [](int Nc, int Kr) { const int tiles = ceil_div(Nc, COCR_FO_BM) * ceil_div(Kr, COCR_FO_BN); return std::max(1, std::min(32, 512 / tiles)); };
+    size_t split_floats = 0;
+    for (auto nk : {std::pair<int, int>{ff, D}, {D, ff}, {D, D}, {2 * D, D}, {C, C}, {D, C * F}, {ncls, D}})
+        split_floats = std::max(split_floats, (size_t)wg_splits(nk.first, nk.second) * nk.first * nk.second);
+    const size_t oSplit = rsv(split_floats), oLinePart = rsv((size_t)N * std::max((size_t)R * D, (size_t)D * K));
     if (need > t->ws_bytes) {
         HIP_TRY(hipDeviceSynchronize());
         if (t->ws) (void)hipFree(t->ws);
@@ -217,11 +223,16 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     };
     // dW += dY^T X, db += colsum(dY), dX = dY W   (dX null: not wanted).  dY (rows, Nc), X (rows, Kr)
     auto lin_bwd = [&](const float *dY, const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *dX) -> int {
-        const int rp = round_up(rows, 32);
+        const int splits = wg_splits(Nc, Kr), rp = round_up(rows, 32 * splits);
         int r;
         transpose(dY, WS(oTA), rows, Nc, rp);
         transpose(X, WS(oTB), rows, Kr, rp);
-        if ((r = gemm(WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, Gp(w), Kr, nullptr))) return r;
+        if (splits == 1) {
+            if ((r = gemm(WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, Gp(w), Kr, nullptr))) return r;
+        } else {
+            GEMM_TRY(launch_gemm_splitk<float>(s, WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, splits, WS(oSplit)));
+            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 256)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
+        }
         if (!b.empty()) colsum(dY, nullptr, rows, Nc, Gp(b), 0);
         if (dX) {
             const int np = round_up(Nc, 4);
@@ -385,7 +396,8 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             copy(Gp(key(l, "2.module.sequential.5.weight")), WS(oVec) + D, D);
             hipLaunchKernelGGL(k_bn_bwd, grid1(MD), dim3(256), 0, s, WS(oDc), WS(a.xhat), Pp(key(l, "2.module.sequential.5.weight")), WS(a.bnr), WS(oVec),
                                WS(oVec) + D, WS(oDe), M, D);                                                  // d dwo
-            hipLaunchKernelGGL(k_dw1d_bwd_w, dim3(ceil_div(D, 64), K), dim3(64), 0, s, WS(oDe), WS(a.g), Gp(key(l, "2.module.sequential.4.conv.weight")), N, T, D, K);
+            hipLaunchKernelGGL(k_dw1d_bwd_w, dim3(ceil_div(D, 64), K, N), dim3(64), 0, s, WS(oDe), WS(a.g), WS(oLinePart), N, T, D, K);
+            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(D * K, 256)), dim3(256), 0, s, WS(oLinePart), Gp(key(l, "2.module.sequential.4.conv.weight")), N, D * K, 0);
             hipLaunchKernelGGL(k_dw1d_bwd_in, grid1(MD), dim3(256), 0, s, WS(oDe), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(oDc), N, T, D, K);   // d g
             hipLaunchKernelGGL(k_glu_bwd, grid1(MD), dim3(256), 0, s, WS(a.ga), WS(oDc), WS(oDwide), M, D);                                              // d a (M, 2D)
             if ((rc = lin_bwd(WS(oDwide), WS(a.xn3), key(l, "2.module.sequential.2.conv.weight"), key(l, "2.module.sequential.2.conv.bias"), M, 2 * D, D, WS(oDc)))) return rc;
@@ -404,7 +416,8 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             hipLaunchKernelGGL(k_attn_bwd_cols, dim3((unsigned)((arows + 3) / 4)), dim3(256), 0, s, WS(oDc), WS(a.q), ub, WS(a.attn), WS(oDsb), WS(oDe), WS(oDa),
                                arows, T, Hh, dh, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));            // d k -> oDe, d v -> oDa
             (void)hipMemsetAsync(WS(oDP), 0, (size_t)Rp * D * 4, s);
-            hipLaunchKernelGGL(k_attn_bwd_pos, dim3(ceil_div(R * Hh, 4)), dim3(256), 0, s, WS(a.q), vbp, WS(oDsb), WS(oDP), N, T, Hh, dh);
+            hipLaunchKernelGGL(k_attn_bwd_pos, dim3(ceil_div(R * Hh, 4), N), dim3(256), 0, s, WS(a.q), vbp, WS(oDsb), WS(oLinePart), N, T, Hh, dh);
+            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(R * D, 256)), dim3(256), 0, s, WS(oLinePart), WS(oDP), N, R * D, 0);
             colsum(du_part, nullptr, M, D, Gp(key(l, "1.module.attention.u_bias")), 0);
             colsum(dvb_part, nullptr, M, D, Gp(key(l, "1.module.attention.v_bias")), 0);
             hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, du_part, dvb_part, 1.0f, MD);                 // d q

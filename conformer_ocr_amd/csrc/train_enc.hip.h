@@ -52,8 +52,8 @@ __global__ static void k_pad_cols(const float *__restrict__ in, float *__restric
         out[i] = c < C ? in[(i / ldo) * C + c] : 0.f;
     }
 }
-// column sums of a (M, N) matrix, optionally of the elementwise product a .* b: part[chunk][n] over 256-row chunks, then out[n] (+)= sum of chunks
-#define COCR_CS_ROWS 256
+// column sums of a (M, N) matrix, optionally of the elementwise product a .* b: part[chunk][n] over 64-row chunks, then out[n] (+)= sum of chunks
+#define COCR_CS_ROWS 64
 __global__ static void k_colsum_partial(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
     if (n >= N) return;
@@ -249,21 +249,21 @@ __global__ static void k_attn_bwd_cols(const float *__restrict__ dctx, const flo
         dv[((size_t)b * T + j) * D + h * dh + d] = a2;
     }
 }
-// backward, positional table: one wave per (row r, head): dP[r, h, :] = sum over lines and the diagonal i - j = T-1-r of ds_ij (q_i + vb)
-__global__ static void k_attn_bwd_pos(const float *__restrict__ q, const float *__restrict__ vb, const float *__restrict__ dsb, float *__restrict__ dP,
+// backward, positional table: one wave per (row r, head) of ONE line (blockIdx.y): part[b][r, h, :] = sum over the diagonal i - j = T-1-r of
+// ds_ij (q_i + vb); summed over the lines by k_colsum_final
+__global__ static void k_attn_bwd_pos(const float *__restrict__ q, const float *__restrict__ vb, const float *__restrict__ dsb, float *__restrict__ part,
                                       int N, int T, int H, int dh) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    const int id = blockIdx.x * wpb + wave;             // r * H + h
+    const int id = blockIdx.x * wpb + wave, b = blockIdx.y;             // id = r * H + h
     if (id >= (2 * T - 1) * H) return;
     const int D = H * dh, r = id / H, h = id - r * H, off = T - 1 - r;      // i - j = off
     const int i0 = max(0, off), i1 = min(T, T + off);
     for (int d = lane; d < dh; d += 64) {
         float acc = 0.f;
         const float vd = vb[h * dh + d];
-        for (int b = 0; b < N; ++b)
-            for (int i = i0; i < i1; ++i)
-                acc = fmaf(dsb[(((size_t)b * H + h) * T + i) * T + (i - off)], q[((size_t)b * T + i) * D + h * dh + d] + vd, acc);
-        dP[(size_t)r * D + h * dh + d] = acc;
+        for (int i = i0; i < i1; ++i)
+            acc = fmaf(dsb[(((size_t)b * H + h) * T + i) * T + (i - off)], q[((size_t)b * T + i) * D + h * dh + d] + vd, acc);
+        part[((size_t)b * (2 * T - 1) + r) * D + h * dh + d] = acc;
     }
 }
 
@@ -294,15 +294,15 @@ __global__ static void k_dw1d_bwd_in(const float *__restrict__ dout, const float
         dg[i] = acc;
     }
 }
-// dw[c, tau] = sum over lines and frames of dout[b, t, c] g[b, t + tau - pad, c]: thread = (c, tau), rows in order
-__global__ static void k_dw1d_bwd_w(const float *__restrict__ dout, const float *__restrict__ g, float *__restrict__ dw, int N, int T, int D, int K) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, tau = blockIdx.y, pad = (K - 1) / 2;
+// dw[c, tau] = sum over lines and frames of dout[b, t, c] g[b, t + tau - pad, c]: thread = (c, tau) of ONE line (blockIdx.z), frames in order;
+// part[b][c K + tau], summed over the lines by k_colsum_final
+__global__ static void k_dw1d_bwd_w(const float *__restrict__ dout, const float *__restrict__ g, float *__restrict__ part, int N, int T, int D, int K) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, tau = blockIdx.y, b = blockIdx.z, pad = (K - 1) / 2;
     if (c >= D) return;
     float acc = 0.f;
-    for (int b = 0; b < N; ++b)
-        for (int t = max(0, pad - tau); t < min(T, T + pad - tau); ++t)
-            acc = fmaf(dout[((size_t)b * T + t) * D + c], g[((size_t)b * T + t + tau - pad) * D + c], acc);
-    dw[c * K + tau] = acc;
+    for (int t = max(0, pad - tau); t < min(T, T + pad - tau); ++t)
+        acc = fmaf(dout[((size_t)b * T + t) * D + c], g[((size_t)b * T + t + tau - pad) * D + c], acc);
+    part[(size_t)b * D * K + c * K + tau] = acc;
 }
 
 // ---- BatchNorm1d, train mode (convolution.py:141) -------------------------------------------------------------------------------------------------
