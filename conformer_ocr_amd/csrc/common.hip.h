@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+typedef __attribute__((address_space(3))) void *lds_ptr_t;            // operands of __builtin_amdgcn_global_load_lds (LDS-DMA)
+typedef __attribute__((address_space(1))) const void *gbl_ptr_t;
+
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

@@ -234,19 +234,33 @@ __global__ __launch_bounds__(64) void ctc_beam_kernel(const float *__restrict__ 
 
 
 // ---- prefix beam search, restructured (same semantics and tie rules as ctc_beam_kernel above) ---------------------------
-// The kernel above evaluates all beam x C candidates of a frame and selects with `beam` full scans: 150 us per frame.  Two
+// The kernel above evaluates all beam x C candidates of a frame and selects with `beam` full scans: 150 us per frame.  Three
 // observations remove almost all of that work without changing any decision:
-//   * log-softmax and the ranking of the classes of a frame do not depend on the beam: phase A computes lp[t][:] and the
-//     K = min(beam + 1, C - 1) best non-blank classes of every frame (ties: smaller class first) with all four waves, frames
-//     in parallel;
-//   * an extension (i, c) scores tot_i + lp[c] (p_b,i + lp[c] if c repeats prefix i's last label), so within one parent the
-//     extensions rank like the classes: an extension outside the K best classes has at least beam + 1 better-ranked extensions
-//     of the SAME parent (same score offset or better, smaller position on ties) and can never be among the `beam` survivors.
-//     Phase B (one wave, frames in order) therefore ranks beam x K + beam candidates instead of beam x C.  Folding (an extension
-//     that equals another live prefix q adds to q's stay candidate, whatever its class rank) is found from q's side: the only
-//     possible parent is the live prefix whose hash, extended by q's last label, equals q's hash.
-// Keys: (monotone u32 image of the score) << 32 | ~position -- one 64-bit wave maximum per selection round, by DPP.
+//   * log-softmax and the ranking of the classes of a frame do not depend on the beam: ctc_beam_rank_kernel (one workgroup per
+//     frame, the whole batch in parallel) writes a 2 KB record per frame: lp[256], the rank of every class, the
+//     K = min(beam + 1, C - 1) best non-blank classes (ties: smaller class first) with their lp, and log Z;
+//   * an extension (i, c) scores tot_i + lp[c] (p_b,i + lp[c] if c repeats prefix i's last label) and the live prefixes are
+//     sorted by tot (they are the previous frame's survivors in rank order).  Extension (i, r) -- prefix i, the class of rank r
+//     -- is therefore beaten by every (i', r') with i' <= i, r' <= r other than itself (score >= in float arithmetic, which is
+//     monotone, and a smaller position i' * C + c' on ties), except by the at most one repeat-demoted extension per prefix; an
+//     extension that was folded away is replaced in that count by the stay candidate that absorbed it (score >=, position <=).
+//     At least (i + 1) * r - 1 candidates rank above it, so it can survive only if (i + 1) * r <= beam: for beam 16 that is a
+//     STATIC set of 66 extensions; with the 16 stay candidates, 82 candidates per frame instead of 16 x 256;
+//   * the survivors are found without any serial selection round: every lane holds its candidates' 64-bit keys
+//     ((monotone image of the score) << 32 | ~position: unique), all keys go through LDS once, and a candidate's rank is the
+//     number of larger keys (one v_cmp_gt_u64 + add per pair).  The candidate of rank R < beam writes the state of next frame's
+//     prefix R itself (including what that prefix needs from the next frame's record), so a frame is three LDS round trips.
+// Folding (an extension that equals another live prefix q adds to q's stay candidate, whatever its class rank) is found from
+// q's side: the only possible parent is the live prefix whose hash equals the hash of q without its last label; q's lane then
+// clears that extension's key in LDS (its slot follows from the rank of q's last label in the frame's record).
+// The walk kernel is one wave per line; frame records stream into a 4-deep LDS ring by LDS-DMA three frames ahead, and the
+// back-pointers stay in LDS (global memory when T * beam is too large for that), so no global latency is on the serial path.
 #define COCR_BEAM_KMAX (COCR_BEAM_MAX + 1)
+#define COCR_BEAM_REC 2048          // bytes per (line, frame): lp[256] f32 | rank[256] u8 | top class[64] i32 | top lp[64] f32 | log Z, pad
+#define COCR_BEAM_REC_RK 1024
+#define COCR_BEAM_REC_TC 1280
+#define COCR_BEAM_REC_TL 1536
+#define COCR_BEAM_REC_LZ 1792
 
 __device__ __forceinline__ unsigned long long beam_key(float score, unsigned pos) {
     if (!(score > -INFINITY)) return 0ull;
@@ -254,314 +268,251 @@ __device__ __forceinline__ unsigned long long beam_key(float score, unsigned pos
     u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
 }
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
-    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-    return o > v ? o : v;
-}
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
-    return o > v ? o : v;
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-    v = dpp_max_u32<0xB1, 0xF>(v);
-    v = dpp_max_u32<0x4E, 0xF>(v);
-    v = dpp_max_u32<0x141, 0xF>(v);
-    v = dpp_max_u32<0x140, 0xF>(v);
-    v = dpp_max_u32<0x142, 0xA>(v);
-    v = dpp_max_u32<0x143, 0xC>(v);
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-// maximum of 64-bit keys as two 32-bit maxima: the score word first, then the position word among the lanes that hold it
-__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
-    const unsigned hi = (unsigned)(v >> 32), mhi = wave_max_u32(hi);
-    const unsigned long long owners = __builtin_amdgcn_ballot_w64(hi == mhi);
-    unsigned mlo;
-    if (__builtin_popcountll(owners) == 1)                   // the usual case: one lane holds the best score -- its position by v_readlane
-        mlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, (int)__builtin_ctzll(owners));
-    else
-        mlo = wave_max_u32(hi == mhi ? (unsigned)v : 0u);    // equal scores: the smallest position (largest ~position) wins
-    return ((unsigned long long)mhi << 32) | mlo;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-    v = dpp_max_u64<0xB1, 0xF>(v);
-    v = dpp_max_u64<0x4E, 0xF>(v);
-    v = dpp_max_u64<0x141, 0xF>(v);
-    v = dpp_max_u64<0x140, 0xF>(v);
-    v = dpp_max_u64<0x142, 0xA>(v);
-    v = dpp_max_u64<0x143, 0xC>(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
+
+// C <= 256.  One workgroup per frame of the batch; thread c owns class c.
+__global__ __launch_bounds__(256) void ctc_beam_rank_kernel(const float *__restrict__ logits, int T, int C, const int32_t *__restrict__ lens, int K,
+                                                            unsigned char *__restrict__ rec_all) {
+    __shared__ __attribute__((aligned(16))) unsigned long long key_s[256];
+    __shared__ float e_s[256], tl_s[64];
+    __shared__ int tc_s[64];
+    const int f = blockIdx.x, n = f / T, t = f - n * T, c = threadIdx.x, lane = c & 63;
+    if (t >= min(max(lens[n], 0), T)) return;
+    unsigned char *rec = rec_all + (size_t)f * COCR_BEAM_REC;
+    const float x = c < C ? logits[(size_t)f * C + c] : -INFINITY;
+    e_s[c] = x;
+    if (c < 64) { tc_s[c] = 0; tl_s[c] = -INFINITY; }
+    __syncthreads();
+    // the frame's maximum and sum in the lane-strided order of ctc_beam_kernel (every wave computes both: no second exchange)
+    float xs[4], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { xs[j] = e_s[lane + 64 * j]; mx = fmaxf(mx, xs[j]); }
+    mx = wave_max(mx);
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (lane + 64 * j < C) sm += expf(xs[j] - mx);
+    const float lz = mx + logf(wave_sum(sm));
+    const float l = c < C ? (x - mx) - (lz - mx) : -INFINITY;
+    reinterpret_cast<float *>(rec)[c] = l;
+    const unsigned long long key = (c >= 1 && c < C) ? beam_key(l, (unsigned)c) : 0ull;      // (-inf lp: key 0, never ranked)
+    key_s[c] = key;
+    __syncthreads();
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 256; j += 2) {
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(&key_s[j]);
+        rank += (kk.x > key) + (kk.y > key);
+    }
+    rec[COCR_BEAM_REC_RK + c] = (unsigned char)(key ? min(rank, 255) : 255);
+    if (key && rank < K) { tc_s[rank] = c; tl_s[rank] = l; }
+    __syncthreads();
+    if (c < 64) {
+        reinterpret_cast<int32_t *>(rec + COCR_BEAM_REC_TC)[c] = tc_s[c];                    // 0 = no further class with a finite score
+        reinterpret_cast<float *>(rec + COCR_BEAM_REC_TL)[c] = tl_s[c];
+    }
+    if (c == 0) *reinterpret_cast<float *>(rec + COCR_BEAM_REC_LZ) = lz;
 }
 
-// C <= 256.  Scratch per line: lp_all [T][C] f32, topc [T][COCR_BEAM_KMAX] i32, bp [T][COCR_BEAM_MAX] i32, logz [T] f32.
-__global__ __launch_bounds__(256) void ctc_beam2_kernel(const float *__restrict__ logits, int T, int C, const int32_t *__restrict__ lens, int beam,
-                                                        int32_t *__restrict__ labels, int32_t *__restrict__ starts, int32_t *__restrict__ ends,
-                                                        float *__restrict__ conf, int32_t *__restrict__ counts, int max_per_line,
-                                                        float *__restrict__ lp_all_, int32_t *__restrict__ topc_all, int32_t *__restrict__ bp_all,
-                                                        float *__restrict__ logz_all, unsigned long long *dbg) {
-    constexpr int NB = COCR_BEAM_MAX, KM = COCR_BEAM_KMAX;
-    __shared__ unsigned long long hash[NB], nhash[NB], ckey[NB * KM];
-    __shared__ float pb[NB], pnb[NB], tot[NB], spb[NB], spnb[NB], mval[NB], lpl[NB], npb[NB], npnb[NB], s_tl[KM];
-    __shared__ int last[NB], nlast[NB], mpos[NB], sel[NB], s_tc[KM];
-    __shared__ int s_cnt;
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One wave per line.  SLOTS = candidates per lane (host: ceil(candidates / 64)).  Dynamic LDS: the line's back-pointers
+// [T][beam] and the label stack of the final walk [T][2] when bp_in_lds, else nothing (bp_gbl: [N][T][COCR_BEAM_MAX]).
+template <int SLOTS>
+__global__ __launch_bounds__(64) void ctc_beam_walk_kernel(const float *__restrict__ logits, int T, int C, const int32_t *__restrict__ lens, int beam, int K,
+                                                           int32_t *__restrict__ labels, int32_t *__restrict__ starts, int32_t *__restrict__ ends,
+                                                           float *__restrict__ conf, int32_t *__restrict__ counts, int max_per_line,
+                                                           const unsigned char *__restrict__ rec_all, int32_t *__restrict__ bp_gbl, int bp_in_lds,
+                                                           unsigned long long *dbg) {
+    constexpr int NB = COCR_BEAM_MAX, KM = COCR_BEAM_KMAX, RING = 4;
+    constexpr unsigned long long PRIME = 1099511628211ull;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[RING][COCR_BEAM_REC];
+    __shared__ __attribute__((aligned(16))) unsigned long long ckey[64 * SLOTS + 2];
+    __shared__ __attribute__((aligned(16))) unsigned long long hash[NB], phash[NB], hx[NB];
+    __shared__ float pb[NB], tot[NB], spb[NB], spnb[NB], lpl[NB];
+    __shared__ int last[NB], off_s[KM + 1], s_cnt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char beam_dyn[];
+    const int n = blockIdx.x, lane = threadIdx.x;
     const int len = min(max(lens[n], 0), T);
     const float *lg = logits + (size_t)n * T * C;
-    float *lp_all = lp_all_ + (size_t)n * T * C;
-    int32_t *topc = topc_all + (size_t)n * T * KM;
-    int32_t *bp = bp_all + (size_t)n * T * NB;
-    float *logz = logz_all + (size_t)n * T;
-    const int K = min(beam + 1, C - 1);
+    const unsigned char *rec = rec_all + (size_t)n * T * COCR_BEAM_REC;
+    int32_t *bpl = reinterpret_cast<int32_t *>(beam_dyn);                      // [T][beam]
+    int32_t *bpg = bp_gbl + (size_t)n * T * NB;                                // [T][NB]
+    auto fence = [&]() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
 
-    // ---- phase A: frames in parallel (4 waves): log-softmax and the K best non-blank classes of each frame
-    for (int t = wave; t < len; t += 4) {
-        float x[4], mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int c = lane + 64 * j; x[j] = c < C ? lg[(size_t)t * C + c] : -INFINITY; mx = fmaxf(mx, x[j]); }
-        mx = wave_max(mx);
-        float sm = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (lane + 64 * j < C) sm += expf(x[j] - mx);
-        const float lz = mx + logf(wave_sum(sm));
-        unsigned long long key[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = lane + 64 * j;
-            const float l = (x[j] - mx) - (lz - mx);
-            if (c < C) lp_all[(size_t)t * C + c] = l;
-            key[j] = (c >= 1 && c < C) ? beam_key(l, (unsigned)c) : 0ull;      // (-inf lp: key 0, never ranked)
-        }
-        if (lane == 0) logz[t] = lz;
-        for (int r = 0; r < K; ++r) {
-            unsigned long long best = key[0];
-#pragma unroll
-            for (int j = 1; j < 4; ++j) best = key[j] > best ? key[j] : best;
-            const unsigned long long top = wave_max_key(best);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (key[j] == top && top) key[j] = 0ull;
-            if (lane == 0) topc[(size_t)t * KM + r] = top ? (int)(0xFFFFFFFFu - (unsigned)top) : 0;      // 0 = no further class with finite score
-        }
+    // frame records: global -> LDS ring, two 1 KB LDS-DMA instructions per frame, issued three frames ahead
+    auto request = [&](int t) {
+        const unsigned char *src = rec + (size_t)min(t, max(len - 1, 0)) * COCR_BEAM_REC + lane * 16;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(&ring[t & (RING - 1)][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + 1024), (lds_ptr_t)(&ring[t & (RING - 1)][1024]), 16, 0, 0);
+    };
+    if (len > 0) { request(0); request(1); request(2); }
+
+    // the static candidate set: extension (i, r) is slot off[r] + i for i < cnt(r) = (r ? min(beam, beam / r) : beam); then the stays
+    if (lane == 0) {
+        int o = 0;
+        for (int r = 0; r < K; ++r) { off_s[r] = o; o += r ? min(beam, beam / r) : beam; }
+        off_s[K] = o;
     }
-    __threadfence_block();
-    __syncthreads();
-    if (wave != 0) return;
+    for (int j = lane; j < 64 * SLOTS + 2; j += 64) ckey[j] = 0ull;
+    if (lane < NB) {
+        const bool root = lane == 0;
+        pb[lane] = root ? 0.f : -INFINITY; tot[lane] = root ? 0.f : -INFINITY; spb[lane] = -INFINITY; spnb[lane] = -INFINITY; lpl[lane] = 0.f;
+        last[lane] = 0; hash[lane] = root ? 1469598103934665603ull : 0ull; phash[lane] = 0ull; hx[lane] = root ? 1469598103934665603ull * PRIME : 0ull;
+    }
+    fence();
+    const int NE = off_s[K], NC = NE + beam, ncp = (NC + 1) & ~1;
+    int ci[SLOTS], cr[SLOTS];                                                  // slot s = lane + 64 sl: extension (ci, cr), or stay of prefix ci (cr = -1), or nothing (ci = -1)
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int s = lane + 64 * sl;
+        ci[sl] = -1; cr[sl] = -1;
+        if (s < NE) { int r = 0; while (off_s[r + 1] <= s) ++r; cr[sl] = r; ci[sl] = s - off_s[r]; }
+        else if (s < NC) ci[sl] = s - NE;
+    }
+    if (len > 0) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        // frame 0 has landed
+        if (lane == 0) spb[0] = reinterpret_cast<const float *>(&ring[0][0])[0];                 // tot (0) + lp[blank] of frame 0
+        fence();
+    }
 
-    // ---- phase B: one wave walks the frames
-    __shared__ unsigned long long hx[NB];                    // hash[i] * prime: an extension's hash is hx[i] + (class + 1)
-    if (lane == 0) { pb[0] = 0.f; pnb[0] = -INFINITY; last[0] = 0; hash[0] = 1469598103934665603ull; }
-    int nb = 1;
-    auto lds_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
-    // this lane's extension candidates j = lane + 64 s: (parent j / K, class rank j % K); in registers for up to SLOTS per lane
-    constexpr int SLOTS = 6;
-    const bool in_regs = beam * K <= 64 * SLOTS;
-    int ci[SLOTS], cr[SLOTS];
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) { const int j = lane + 64 * sl; ci[sl] = j / K; cr[sl] = j - ci[sl] * K; }
-    // The frame's log-softmax row and class ranking live in LDS, one frame ahead (global latency would otherwise sit on the
-    // serial path twice per frame: ranking -> lp[class])
-    __shared__ float lp_s[2][256];
-    __shared__ int tc_s[2][KM];
-    float nlp[4];
-    int ntc = 0;
-    auto request_frame = [&](int t) {
-        const int tt = min(t, max(len - 1, 0));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int c = lane + 64 * j; nlp[j] = c < C ? lp_all[(size_t)tt * C + c] : 0.f; }
-        ntc = lane < K ? topc[(size_t)tt * KM + lane] : 0;
-    };
-    auto publish_frame = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lp_s[buf][lane + 64 * j] = nlp[j];
-        if (lane < KM) tc_s[buf][lane] = ntc;
-    };
-    request_frame(0);
-    publish_frame(0);
-    lds_sync();
 #ifdef COCR_CHAIN_STAMPS_BUILD
-    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define BSTAMP(k) { const unsigned long long now = __builtin_readcyclecounter(); acc_t[k] += now - tprev; tprev = now; }
 #else
 #define BSTAMP(k)
 #endif
     for (int t = 0; t < len; ++t) {
-        const float *lp = lp_s[t & 1];
-        request_frame(t + 1);                                    // in flight during this frame
-        const float lp0 = lp[0];
-        if (lane < K) { const int c = tc_s[t & 1][lane]; s_tc[lane] = c; s_tl[lane] = c ? lp[c] : -INFINITY; }
-        if (lane < nb) {
-            const float p_b = pb[lane], p_nb = pnb[lane], tt = lse2(p_b, p_nb);
-            const int li = last[lane];
-            const float l = li > 0 ? lp[li] : 0.f;
-            tot[lane] = tt; lpl[lane] = l;
-            spb[lane] = tt + lp0;
-            spnb[lane] = li > 0 ? p_nb + l : -INFINITY;
-            mval[lane] = -INFINITY; mpos[lane] = 0x7fffffff;
-            hx[lane] = hash[lane] * 1099511628211ull;
-        }
-        lds_sync();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // (the ring slot of frame t - 1 is read no more)
+        request(t + 3);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        // frames <= t + 1 have landed (in-order completion)
         BSTAMP(0)
-        // folds: extension (i, last_q) of parent i equals live prefix q
-        for (int pi = lane; pi < beam * beam; pi += 64) {
-            const int q = pi / beam, i = pi - q * beam;              // (the compiler hoists this out of the frame loop)
-            if (q >= nb || i >= nb) continue;
-            const int lq = last[q];
-            if (i != q && lq > 0 && hx[i] + (unsigned long long)(lq + 1) == hash[q]) {
-                const float add = (lq == last[i] ? pb[i] : tot[i]) + lpl[q];
-                if (add > -INFINITY) { mval[q] = add; mpos[q] = i * C + lq; }
-            }
-        }
-        lds_sync();
-        BSTAMP(1)
-        // candidates: extensions (i, r-th class) unless folded; then this lane's stay candidate
-        const int ncand = nb * K;
-        unsigned long long ck[SLOTS];
-        auto ext_key = [&](int i, int r) -> unsigned long long {
-            const int c = s_tc[r];
-            if (c <= 0) return 0ull;
-            float e = (c == last[i] ? pb[i] : tot[i]) + s_tl[r];
-            const int pos = i * C + c;
-            for (int q = 0; q < nb; ++q) if (mpos[q] == pos) e = -INFINITY;             // folded into q's stay candidate
-            return beam_key(e, (unsigned)pos);
-        };
-        if (in_regs) {
-            float ce[SLOTS];
-            int cpos[SLOTS];
+        const unsigned char *cur = ring[t & (RING - 1)], *nxt = ring[(t + 1) & (RING - 1)];
+        const float *lpn = reinterpret_cast<const float *>(nxt);
+        const int32_t *tcc = reinterpret_cast<const int32_t *>(cur + COCR_BEAM_REC_TC);
+        const float *tlc = reinterpret_cast<const float *>(cur + COCR_BEAM_REC_TL);
+
+        // candidates: keys to LDS; what a winner will need stays in registers
+        float n_pb[SLOTS], n_pnb[SLOTS], n_tot[SLOTS];
+        int n_last[SLOTS], n_bp[SLOTS], zero_slot = -1;
+        unsigned long long n_hash[SLOTS], n_ph[SLOTS];
 #pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                const int i = ci[sl], c = lane + 64 * sl < ncand ? s_tc[cr[sl]] : 0;
-                cpos[sl] = i * C + c;
-                ce[sl] = c > 0 ? (c == last[i] ? pb[i] : tot[i]) + s_tl[cr[sl]] : -INFINITY;
-            }
-            const int my_mpos = lane < nb ? mpos[lane] : 0x7fffffff;                   // folded positions: lane q -> everyone, by v_readlane
-            for (int q = 0; q < nb; ++q) {
-                const int mp = __builtin_amdgcn_readlane(my_mpos, q);
-#pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) if (cpos[sl] == mp) ce[sl] = -INFINITY;
-            }
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) ck[sl] = beam_key(ce[sl], (unsigned)cpos[sl]);
-            // sort the lane's keys (descending): a selection round then looks at ck[0] only
-#pragma unroll
-            for (int a2 = 0; a2 < SLOTS; ++a2)
-#pragma unroll
-                for (int b2 = 0; b2 + 1 < SLOTS - a2; ++b2)
-                    if (ck[b2] < ck[b2 + 1]) { const unsigned long long tmp = ck[b2]; ck[b2] = ck[b2 + 1]; ck[b2 + 1] = tmp; }
-        } else {
-            for (int j = lane; j < ncand; j += 64) { const int i = j / K; ckey[j] = ext_key(i, j - i * K); }
-        }
-        unsigned long long skey = 0ull;
-        if (lane < nb) {
-            const float s_nb = lse2(spnb[lane], mval[lane]);
-            spnb[lane] = s_nb;
-            skey = beam_key(lse2(spb[lane], s_nb), (unsigned)min(lane * C, mpos[lane]));
-        }
-        lds_sync();
-        BSTAMP(2)
-        // the `beam` best keys
-        int nsel = 0;
-        if (in_regs) {
-            // Branch-free rounds: the lane's keys (extensions + its stay candidate) are one sorted list; a round is two 32-bit DPP
-            // maxima over the heads, the owner pops by selects, lane r keeps the r-th key.  Who the key belongs to is decoded
-            // afterwards from its position: class 0 = stay of prefix pos / C; a folded position = stay of the prefix that absorbed
-            // it; anything else = extension (pos / C, pos % C).
-            unsigned long long lk[SLOTS + 1];
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) lk[sl] = ck[sl];
-            lk[SLOTS] = skey;
-#pragma unroll
-            for (int sl = SLOTS; sl > 0; --sl)                    // insert the stay key into the sorted extensions
-                if (lk[sl] > lk[sl - 1]) { const unsigned long long tmp = lk[sl]; lk[sl] = lk[sl - 1]; lk[sl - 1] = tmp; }
-            unsigned long long mykey = 0ull;
-            for (int r = 0; r < beam; ++r) {
-                const unsigned long long top = wave_max_key(lk[0]);
-                if (!top) break;                                  // uniform
-                const bool mine = lk[0] == top;
-#pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) lk[sl] = mine ? lk[sl + 1] : lk[sl];
-                lk[SLOTS] = mine ? 0ull : lk[SLOTS];
-                mykey = lane == r ? top : mykey;
-                ++nsel;
-            }
-            const int pos = (int)(0xFFFFFFFFu - (unsigned)mykey), pi2 = pos / C, pc = pos - pi2 * C;
-            int idx = pc == 0 ? 0x40000000 + pi2 : pos;
-            const int my_mpos2 = lane < nb ? mpos[lane] : 0x7fffffff;
-            for (int q = 0; q < nb; ++q) if (__builtin_amdgcn_readlane(my_mpos2, q) == pos) idx = 0x40000000 + q;
-            if (lane < nsel) sel[lane] = idx;
-        } else {
-            for (int r = 0; r < beam; ++r) {
-                unsigned long long best = skey;
-                int bidx = 0x40000000 + lane;
-                for (int j = lane; j < ncand; j += 64) { const unsigned long long k2 = ckey[j]; if (k2 > best) { best = k2; bidx = j; } }
-                const unsigned long long top = wave_max_key(best);
-                if (!top) break;
-                if (best == top) {                               // keys are unique (positions are): exactly one lane
-                    sel[r] = bidx;
-                    if (bidx >= 0x40000000) skey = 0ull; else ckey[bidx] = 0ull;
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int i = ci[sl], r = cr[sl];
+            unsigned long long key = 0ull;
+            n_pb[sl] = -INFINITY; n_pnb[sl] = -INFINITY; n_tot[sl] = -INFINITY; n_last[sl] = 0; n_bp[sl] = 0; n_hash[sl] = 0ull; n_ph[sl] = 0ull;
+            if (r >= 0) {                                                      // extension of prefix i by the class of rank r
+                const int c = tcc[r], li = last[i];
+                const float e = c > 0 ? (c == li ? pb[i] : tot[i]) + tlc[r] : -INFINITY;
+                key = beam_key(e, (unsigned)(i * C + c));
+                n_pnb[sl] = e; n_tot[sl] = e; n_last[sl] = c; n_bp[sl] = (i << 16) | c;
+                n_hash[sl] = hx[i] + (unsigned long long)(c + 1); n_ph[sl] = hash[i];
+            } else if (i >= 0) {                                               // prefix i stays; an extension equal to it folds into it
+                const int lq = last[i];
+                const unsigned long long ph = phash[i];
+                int iq = -1;
+                for (int j = 0; j < beam; ++j) if (hash[j] == ph && j != i) iq = j;
+                float mval = -INFINITY;
+                int mpos = 0x7fffffff;
+                if (lq > 0 && iq >= 0) {
+                    const float add = (lq == last[iq] ? pb[iq] : tot[iq]) + lpl[i];
+                    if (add > -INFINITY) {
+                        mval = add; mpos = iq * C + lq;
+                        const int r2 = cur[COCR_BEAM_REC_RK + lq];
+                        if (r2 < K && iq < off_s[r2 + 1] - off_s[r2]) zero_slot = off_s[r2] + iq;
+                    }
                 }
-                ++nsel;
-                lds_sync();
+                const float s_nb = lse2(spnb[i], mval), sc = lse2(spb[i], s_nb);
+                key = beam_key(sc, (unsigned)min(i * C, mpos));
+                n_pb[sl] = spb[i]; n_pnb[sl] = s_nb; n_tot[sl] = sc; n_last[sl] = lq; n_hash[sl] = hash[i]; n_ph[sl] = ph;
+                n_bp[sl] = mpos < i * C ? ((iq << 16) | lq) : (i << 16);      // first creator
+            }
+            ckey[lane + 64 * sl] = key;
+        }
+        fence();
+        if (zero_slot >= 0) ckey[zero_slot] = 0ull;                            // folded: not a candidate of its own
+        fence();
+        BSTAMP(1)
+        // ranks: the number of larger keys
+        unsigned long long k[SLOTS];
+        int rank[SLOTS], nlive = 0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) { k[sl] = ckey[lane + 64 * sl]; rank[sl] = 0; nlive += __builtin_popcountll(__builtin_amdgcn_ballot_w64(k[sl] != 0ull)); }
+#pragma unroll 4
+        for (int j = 0; j < ncp; j += 2) {
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(&ckey[j]);
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) rank[sl] += (kk.x > k[sl]) + (kk.y > k[sl]);
+        }
+        const int nsel = min(beam, nlive);
+        fence();
+        BSTAMP(2)
+        // the survivors write next frame's prefixes
+        const float lp0n = lpn[0];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int R = rank[sl];
+            if (k[sl] != 0ull && R < beam) {
+                const int nl = n_last[sl];
+                const float l2 = lpn[nl];
+                pb[R] = n_pb[sl]; tot[R] = n_tot[sl]; last[R] = nl; hash[R] = n_hash[sl]; phash[R] = n_ph[sl]; hx[R] = n_hash[sl] * PRIME;
+                spb[R] = n_tot[sl] + lp0n; spnb[R] = nl > 0 ? n_pnb[sl] + l2 : -INFINITY; lpl[R] = nl > 0 ? l2 : 0.f;
+                if (bp_in_lds) bpl[t * beam + R] = n_bp[sl]; else bpg[(size_t)t * NB + R] = n_bp[sl];
             }
         }
-        lds_sync();
+        if (lane >= nsel && lane < beam) {                                     // fewer candidates than the beam holds
+            pb[lane] = -INFINITY; tot[lane] = -INFINITY; spb[lane] = -INFINITY; spnb[lane] = -INFINITY; lpl[lane] = 0.f;
+            last[lane] = 0; hash[lane] = 0ull; phash[lane] = 0ull; hx[lane] = 0ull;
+        }
+        fence();
         BSTAMP(3)
-        // next beam + back-pointers
-        if (lane < nsel) {
-            const int idx = sel[lane];
-            if (idx >= 0x40000000) {
-                const int q = idx - 0x40000000, mp = mpos[q];
-                npb[lane] = spb[q]; npnb[lane] = spnb[q]; nlast[lane] = last[q]; nhash[lane] = hash[q];
-                bp[(size_t)t * NB + lane] = mp < q * C ? (((mp / C) << 16) | (mp % C)) : (q << 16);      // first creator
-            } else {
-                int i, c;
-                if (in_regs) { i = idx / C; c = idx - i * C; }             // a position
-                else { i = idx / K; c = s_tc[idx - i * K]; }               // a candidate slot
-                npb[lane] = -INFINITY; npnb[lane] = (c == last[i] ? pb[i] : tot[i]) + lp[c]; nlast[lane] = c;
-                nhash[lane] = hx[i] + (unsigned long long)(c + 1);
-                bp[(size_t)t * NB + lane] = (i << 16) | c;
-            }
-        }
-        lds_sync();
-        if (lane < nsel) { pb[lane] = npb[lane]; pnb[lane] = npnb[lane]; last[lane] = nlast[lane]; hash[lane] = nhash[lane]; }
-        nb = nsel;
-        publish_frame((t + 1) & 1);
-        lds_sync();
-        BSTAMP(4)
     }
-#ifdef COCR_CHAIN_STAMPS_BUILD
-    if (dbg && n == 0 && lane == 0) for (int k2 = 0; k2 < 5; ++k2) dbg[k2] = acc_t[k2] + 1;
-#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- best prefix: walk the back-pointers (one lane), then ends / confidences in parallel over the labels
     int32_t *olab = labels + (size_t)n * max_per_line, *ost = starts + (size_t)n * max_per_line;
-    if (lane == 0) {
+    if (bp_in_lds) {
+        int32_t *stk = bpl + (size_t)T * beam;                                 // [T][2] (label, frame), last label first
+        if (lane == 0) {
+            int cnt = 0, e = 0;
+            for (int t = len - 1; t >= 0; --t) {
+                const int v = bpl[t * beam + e];
+                if (v & 0xffff) { stk[2 * cnt] = v & 0xffff; stk[2 * cnt + 1] = t; ++cnt; }
+                e = v >> 16;
+            }
+            s_cnt = cnt;
+            counts[n] = cnt;
+        }
+        fence();
+        const int cnt = s_cnt;
+        for (int k2 = lane; k2 < min(cnt, max_per_line); k2 += 64) { olab[k2] = stk[2 * (cnt - 1 - k2)]; ost[k2] = stk[2 * (cnt - 1 - k2) + 1]; }
+    } else if (lane == 0) {
         int cnt = 0, e = 0;
         for (int t = len - 1; t >= 0; --t) {
-            const int v = bp[(size_t)t * NB + e];
+            const int v = bpg[(size_t)t * NB + e];
             if (v & 0xffff) ++cnt;
             e = v >> 16;
         }
         s_cnt = cnt;
-        int k = cnt;
+        int k2 = cnt;
         e = 0;
         for (int t = len - 1; t >= 0; --t) {
-            const int v = bp[(size_t)t * NB + e];
-            if (v & 0xffff) { --k; if (k < max_per_line) { olab[k] = v & 0xffff; ost[k] = t; } }
+            const int v = bpg[(size_t)t * NB + e];
+            if (v & 0xffff) { --k2; if (k2 < max_per_line) { olab[k2] = v & 0xffff; ost[k2] = t; } }
             e = v >> 16;
         }
         counts[n] = cnt;
     }
     __threadfence_block();
-    lds_sync();
+    fence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const int cnt = min(s_cnt, max_per_line);
-    for (int k = lane; k < cnt; k += 64) {
-        const int c = olab[k], s0 = ost[k], limit = k + 1 < cnt ? ost[k + 1] : len;
+    for (int k2 = lane; k2 < cnt; k2 += 64) {
+        const int c = olab[k2], s0 = ost[k2], limit = k2 + 1 < cnt ? ost[k2 + 1] : len;
         int e = s0;
         while (e + 1 < limit && lg[(size_t)(e + 1) * C + c] > lg[(size_t)(e + 1) * C]) ++e;
         float mxp = -INFINITY;
-        for (int t = s0; t <= e; ++t) mxp = fmaxf(mxp, lg[(size_t)t * C + c] - logz[t]);
-        ends[(size_t)n * max_per_line + k] = e;
-        conf[(size_t)n * max_per_line + k] = expf(mxp);
+        for (int t = s0; t <= e; ++t) mxp = fmaxf(mxp, lg[(size_t)t * C + c] - *reinterpret_cast<const float *>(rec + (size_t)t * COCR_BEAM_REC + COCR_BEAM_REC_LZ));
+        ends[(size_t)n * max_per_line + k2] = e;
+        conf[(size_t)n * max_per_line + k2] = expf(mxp);
     }
+#ifdef COCR_CHAIN_STAMPS_BUILD
+    BSTAMP(4)
+    if (dbg && n == 0 && lane == 0) for (int k2 = 0; k2 < 5; ++k2) dbg[k2] = acc_t[k2] + 1;
+#endif
 }

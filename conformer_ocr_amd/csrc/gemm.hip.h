@@ -27,9 +27,6 @@
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-typedef __attribute__((address_space(1))) const void *gbl_ptr_t;
-
 // XCD-aware workgroup remap (8 XCDs, private L2 each; workgroups are dealt round-robin, so ids b and b+8
 // share an XCD).  Logical tile L = chunk(b % 8) + b / 8 gives every XCD a CONTIGUOUS run of logical tiles:
 // all column tiles of a row block then read that row block's A rows through ONE L2 instead of eight.
