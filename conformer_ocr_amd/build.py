@@ -104,6 +104,9 @@ def _build_to(LIB: str, verbose: bool) -> str:
     with open(LIB + '.srchash.tmp', 'w') as fp:
         fp.write(src_hash + '\n')
     os.replace(LIB + '.srchash.tmp', LIB + '.srchash')
+    for d in os.listdir(os.path.join(LIB_DIR, 'obj')):                # objects of earlier source states
+        if d != src_hash:
+            shutil.rmtree(os.path.join(LIB_DIR, 'obj', d), ignore_errors=True)
     return LIB
 
 

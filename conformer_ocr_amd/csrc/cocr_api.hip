@@ -277,8 +277,8 @@ extern "C" void cocr_destroy(cocr_model *m) {
         (void)hipDeviceSynchronize();
         fprintf(stderr, "frontend stamps:");
         for (int i = 129; i < 192 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[128]);
-        fprintf(stderr, "\nbeam walk cycles (wait for the frame, candidates, ranks, update, tail):");
-        for (int i = 240; i < 245 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i]);
+        fprintf(stderr, "\nbeam walk cycles of the stay wave, then of extension wave 0 (pairs + reads, keys, barrier + ranks, update, tail):");
+        for (int i = 240; i < 250 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i]);
         fprintf(stderr, "\nattention stamps:");
         for (int i = 193; i < 240 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[192]);
         fprintf(stderr, "\n");
@@ -1295,9 +1295,6 @@ extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, i
     if (rc) return rc;
     const bool fast = ncls <= 256 && !m->beam_ref;            // ctc_beam_rank_kernel + ctc_beam_walk_kernel: frames ranked in parallel, a static pruned candidate set per frame
     const int K = std::min(beam + 1, ncls - 1);
-    int ncand = beam;                                         // stays + the extensions (i, r) with (i + 1) * r <= beam
-    for (int r = 0; r < K; ++r) ncand += r ? std::min(beam, beam / r) : beam;
-    const int slots = (ncand + 63) / 64;
     // scratch: back-pointers [N][T][COCR_BEAM_MAX] i32, then log Z [N][T] (exhaustive kernel) or the frame records (fast)
     const size_t need = (size_t)N * T * ((size_t)COCR_BEAM_MAX * 4 + (fast ? (size_t)COCR_BEAM_REC : 4));
     if (need > m->beam_cap) {
@@ -1313,13 +1310,13 @@ extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, i
         const size_t dyn = (size_t)T * ((size_t)beam * 4 + 8);                 // back-pointers + the label stack of the final walk, in LDS when they fit
         const int bp_in_lds = dyn <= 96 * 1024;
         hipLaunchKernelGGL(ctc_beam_rank_kernel, dim3(N * T), dim3(256), 0, s, logits, T, ncls, m->d_lens_cur, K, rec);
-#define COCR_BEAM_WALK(SL)                                                                                                                      \
-    {                                                                                                                                           \
-        if (bp_in_lds) HIP_TRY(raise_lds_limit((const void *)ctc_beam_walk_kernel<SL>, dyn));                                                   \
-        hipLaunchKernelGGL(ctc_beam_walk_kernel<SL>, dim3(N), dim3(64), bp_in_lds ? dyn : 0, s, logits, T, ncls, m->d_lens_cur, beam, K, labels, \
-                           starts, ends, conf, counts, max_per_line, rec, bp, bp_in_lds, m->stamps ? m->stamps + 240 : nullptr);                \
+#define COCR_BEAM_WALK(SL)                                                                                                                          \
+    {                                                                                                                                               \
+        if (bp_in_lds) HIP_TRY(raise_lds_limit((const void *)ctc_beam_walk_kernel<SL>, dyn));                                                       \
+        hipLaunchKernelGGL(ctc_beam_walk_kernel<SL>, dim3(N), dim3(256), bp_in_lds ? dyn : 0, s, logits, T, ncls, m->d_lens_cur, beam, K, labels, starts, \
+                           ends, conf, counts, max_per_line, rec, bp, bp_in_lds, m->stamps ? m->stamps + 240 : nullptr);                            \
     }
-        if (slots <= 1) COCR_BEAM_WALK(1) else if (slots == 2) COCR_BEAM_WALK(2) else COCR_BEAM_WALK(3)
+        if (beam <= 16) COCR_BEAM_WALK(2) else COCR_BEAM_WALK(3)      // candidates per lane of a wave: <= 88 for beam <= 16, <= 184 for beam 32
 #undef COCR_BEAM_WALK
     } else {
         float *logz = reinterpret_cast<float *>(bp + (size_t)N * T * COCR_BEAM_MAX);

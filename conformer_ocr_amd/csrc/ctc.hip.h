@@ -87,11 +87,12 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(int T, const int32_t *
 //      which its labels were appended; ends / confidences follow the oracle's post-pass.
 #define COCR_BEAM_MAX 32
 
+// logaddexp on the hardware's exp2 / log2 (~1 ulp each): max + ln 2 * log2(1 + 2^(-|a - b| log2 e)).  The beam kernels sit on a
+// serial chain of these (two per frame and prefix); the libm log1pf(expf()) form is ~50 dependent instructions, this one 8.
+// -inf operands: |a - b| = inf gives max + 0; a == b (also both -inf) gives max + ln 2 without forming inf - inf.
 __device__ __forceinline__ float lse2(float a, float b) {
-    if (a == -INFINITY) return b;
-    if (b == -INFINITY) return a;
-    const float m = fmaxf(a, b);
-    return m + log1pf(expf(-fabsf(a - b)));
+    const float m = fmaxf(a, b), d = a == b ? 0.f : -fabsf(a - b);
+    return m + 0.6931471805599453f * __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(d * 1.4426950408889634f));
 }
 
 __global__ __launch_bounds__(64) void ctc_beam_kernel(const float *__restrict__ logits, int T, int C, const int32_t *__restrict__ lens, int beam,
@@ -312,163 +313,237 @@ __global__ __launch_bounds__(256) void ctc_beam_rank_kernel(const float *__restr
     if (c == 0) *reinterpret_cast<float *>(rec + COCR_BEAM_REC_LZ) = lz;
 }
 
-// One wave per line.  SLOTS = candidates per lane (host: ceil(candidates / 64)).  Dynamic LDS: the line's back-pointers
-// [T][beam] and the label stack of the final walk [T][2] when bp_in_lds, else nothing (bp_gbl: [N][T][COCR_BEAM_MAX]).
-template <int SLOTS>
-__global__ __launch_bounds__(64) void ctc_beam_walk_kernel(const float *__restrict__ logits, int T, int C, const int32_t *__restrict__ lens, int beam, int K,
-                                                           int32_t *__restrict__ labels, int32_t *__restrict__ starts, int32_t *__restrict__ ends,
-                                                           float *__restrict__ conf, int32_t *__restrict__ counts, int max_per_line,
-                                                           const unsigned char *__restrict__ rec_all, int32_t *__restrict__ bp_gbl, int bp_in_lds,
-                                                           unsigned long long *dbg) {
-    constexpr int NB = COCR_BEAM_MAX, KM = COCR_BEAM_KMAX, RING = 4;
+// One workgroup of four waves per line, one candidate per thread: threads [0, NE) own the extensions (waves 0..2; NE <= 151 for
+// beam 32), threads 192 + q the stay candidate of prefix q (wave 3).  Three barriers per frame: (A) next frame's prefixes are in
+// LDS -> all 256 threads look for fold pairs (one (q, i) hash comparison each for beam <= 16) -> (A2) -> keys -> (B) -> ranks ->
+// the survivors write the prefixes.  Dynamic LDS: the line's back-pointers [T][beam] and the label stack of the final walk
+// [T][2] when bp_in_lds, else nothing (bp_gbl: [N][T][COCR_BEAM_MAX]).
+// One wave alone on its SIMD pays ~7 cycles per DEPENDENT vector instruction and ~8 per compare into a scalar register pair
+// (tools/micro/sgpr_dep.hip), so the rank loop is written out: per step eight independent 64-bit compares into eight scalar
+// pairs, eight add-with-carry, and the next eight keys' LDS reads in flight underneath (15 cycles per key; the compiler's
+// compare / select / add chain: 21, and it waits for every read).
+typedef unsigned long long beam_u64x2 __attribute__((ext_vector_type(2)));
+template <bool LOAD>
+__device__ __forceinline__ void beam_rank_step(int &rank, int &rank2, beam_u64x2 (&nx)[4], const beam_u64x2 (&cu)[4], unsigned long long key, unsigned next_addr) {
+    if (LOAD)
+        asm volatile("ds_read_b128 %2, %14\n\tds_read_b128 %3, %14 offset:16\n\tds_read_b128 %4, %14 offset:32\n\tds_read_b128 %5, %14 offset:48\n\t"
+                     "v_cmp_gt_u64 s[40:41], %6, %15\n\tv_cmp_gt_u64 s[42:43], %7, %15\n\tv_cmp_gt_u64 s[44:45], %8, %15\n\tv_cmp_gt_u64 s[46:47], %9, %15\n\t"
+                     "v_cmp_gt_u64 s[48:49], %10, %15\n\tv_cmp_gt_u64 s[50:51], %11, %15\n\tv_cmp_gt_u64 s[52:53], %12, %15\n\tv_cmp_gt_u64 s[54:55], %13, %15\n\t"
+                     "v_addc_co_u32 %0, vcc, 0, %0, s[40:41]\n\tv_addc_co_u32 %1, vcc, 0, %1, s[42:43]\n\tv_addc_co_u32 %0, vcc, 0, %0, s[44:45]\n\t"
+                     "v_addc_co_u32 %1, vcc, 0, %1, s[46:47]\n\tv_addc_co_u32 %0, vcc, 0, %0, s[48:49]\n\tv_addc_co_u32 %1, vcc, 0, %1, s[50:51]\n\t"
+                     "v_addc_co_u32 %0, vcc, 0, %0, s[52:53]\n\tv_addc_co_u32 %1, vcc, 0, %1, s[54:55]\n\ts_waitcnt lgkmcnt(0)"
+                     : "+v"(rank), "+v"(rank2), "=&v"(nx[0]), "=&v"(nx[1]), "=&v"(nx[2]), "=&v"(nx[3])
+                     : "v"(cu[0].x), "v"(cu[0].y), "v"(cu[1].x), "v"(cu[1].y), "v"(cu[2].x), "v"(cu[2].y), "v"(cu[3].x), "v"(cu[3].y), "v"(next_addr), "v"(key)
+                     : "vcc", "memory", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");
+    else
+        asm volatile("v_cmp_gt_u64 s[40:41], %2, %10\n\tv_cmp_gt_u64 s[42:43], %3, %10\n\tv_cmp_gt_u64 s[44:45], %4, %10\n\tv_cmp_gt_u64 s[46:47], %5, %10\n\t"
+                     "v_cmp_gt_u64 s[48:49], %6, %10\n\tv_cmp_gt_u64 s[50:51], %7, %10\n\tv_cmp_gt_u64 s[52:53], %8, %10\n\tv_cmp_gt_u64 s[54:55], %9, %10\n\t"
+                     "v_addc_co_u32 %0, vcc, 0, %0, s[40:41]\n\tv_addc_co_u32 %1, vcc, 0, %1, s[42:43]\n\tv_addc_co_u32 %0, vcc, 0, %0, s[44:45]\n\t"
+                     "v_addc_co_u32 %1, vcc, 0, %1, s[46:47]\n\tv_addc_co_u32 %0, vcc, 0, %0, s[48:49]\n\tv_addc_co_u32 %1, vcc, 0, %1, s[50:51]\n\t"
+                     "v_addc_co_u32 %0, vcc, 0, %0, s[52:53]\n\tv_addc_co_u32 %1, vcc, 0, %1, s[54:55]"
+                     : "+v"(rank), "+v"(rank2)
+                     : "v"(cu[0].x), "v"(cu[0].y), "v"(cu[1].x), "v"(cu[1].y), "v"(cu[2].x), "v"(cu[2].y), "v"(cu[3].x), "v"(cu[3].y), "v"(key)
+                     : "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");
+}
+__device__ __forceinline__ bool beam_eq64(unsigned long long a, unsigned long long b) {
+    return (((unsigned)a ^ (unsigned)b) | ((unsigned)(a >> 32) ^ (unsigned)(b >> 32))) == 0u;
+}
+
+template <int SL>
+__global__ __launch_bounds__(256) void ctc_beam_walk_kernel(const float *__restrict__ logits, int T, int C, const int32_t *__restrict__ lens, int beam, int K,
+                                                            int32_t *__restrict__ labels, int32_t *__restrict__ starts, int32_t *__restrict__ ends,
+                                                            float *__restrict__ conf, int32_t *__restrict__ counts, int max_per_line,
+                                                            const unsigned char *__restrict__ rec_all, int32_t *__restrict__ bp_gbl, int bp_in_lds,
+                                                            unsigned long long *dbg) {
+    constexpr int NB = COCR_BEAM_MAX, KM = COCR_BEAM_KMAX, RING = 4, STAY0 = 192;
     constexpr unsigned long long PRIME = 1099511628211ull;
     __shared__ __attribute__((aligned(16))) unsigned char ring[RING][COCR_BEAM_REC];
-    __shared__ __attribute__((aligned(16))) unsigned long long ckey[64 * SLOTS + 2];
+    __shared__ __attribute__((aligned(16))) unsigned long long ckey[STAY0 + NB];                 // extensions [0, nep), stays [nep, nep + beam), zeros between
     __shared__ __attribute__((aligned(16))) unsigned long long hash[NB], phash[NB], hx[NB];
-    __shared__ float pb[NB], tot[NB], spb[NB], spnb[NB], lpl[NB];
-    __shared__ int last[NB], off_s[KM + 1], s_cnt;
+    __shared__ __attribute__((aligned(16))) float pb[NB], tot[NB], spb[NB], spnb[NB], lpl[NB];
+    __shared__ __attribute__((aligned(16))) int last[NB], pair_s[NB], live_s[4], off_s[KM + 1], rank_s[64 * SL], s_cnt;
     extern __shared__ __attribute__((aligned(16))) unsigned char beam_dyn[];
-    const int n = blockIdx.x, lane = threadIdx.x;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int len = min(max(lens[n], 0), T);
     const float *lg = logits + (size_t)n * T * C;
     const unsigned char *rec = rec_all + (size_t)n * T * COCR_BEAM_REC;
     int32_t *bpl = reinterpret_cast<int32_t *>(beam_dyn);                      // [T][beam]
     int32_t *bpg = bp_gbl + (size_t)n * T * NB;                                // [T][NB]
-    auto fence = [&]() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
 
-    // frame records: global -> LDS ring, two 1 KB LDS-DMA instructions per frame, issued three frames ahead
+    // frame records: global -> LDS ring, two 1 KB LDS-DMA instructions per frame, issued three frames ahead by wave 2
     auto request = [&](int t) {
         const unsigned char *src = rec + (size_t)min(t, max(len - 1, 0)) * COCR_BEAM_REC + lane * 16;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(&ring[t & (RING - 1)][0]), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + 1024), (lds_ptr_t)(&ring[t & (RING - 1)][1024]), 16, 0, 0);
     };
-    if (len > 0) { request(0); request(1); request(2); }
+    if (wave == 2 && len > 0) { request(0); request(1); request(2); }
 
-    // the static candidate set: extension (i, r) is slot off[r] + i for i < cnt(r) = (r ? min(beam, beam / r) : beam); then the stays
-    if (lane == 0) {
+    // the static candidate set: extension (i, r) is thread off[r] + i for i < cnt(r) = (r ? min(beam, beam / r) : beam)
+    if (tid == 0) {
         int o = 0;
         for (int r = 0; r < K; ++r) { off_s[r] = o; o += r ? min(beam, beam / r) : beam; }
         off_s[K] = o;
     }
-    for (int j = lane; j < 64 * SLOTS + 2; j += 64) ckey[j] = 0ull;
-    if (lane < NB) {
-        const bool root = lane == 0;
-        pb[lane] = root ? 0.f : -INFINITY; tot[lane] = root ? 0.f : -INFINITY; spb[lane] = -INFINITY; spnb[lane] = -INFINITY; lpl[lane] = 0.f;
-        last[lane] = 0; hash[lane] = root ? 1469598103934665603ull : 0ull; phash[lane] = 0ull; hx[lane] = root ? 1469598103934665603ull * PRIME : 0ull;
+    if (tid < STAY0 + NB) ckey[tid] = 0ull;
+    if (tid < NB) {
+        const bool root = tid == 0;
+        pb[tid] = root ? 0.f : -INFINITY; tot[tid] = root ? 0.f : -INFINITY; spb[tid] = -INFINITY; spnb[tid] = -INFINITY; lpl[tid] = 0.f;
+        last[tid] = 0; hash[tid] = root ? 1469598103934665603ull : 0ull; phash[tid] = 0ull; hx[tid] = root ? 1469598103934665603ull * PRIME : 0ull;
+        pair_s[tid] = -1;
     }
-    fence();
-    const int NE = off_s[K], NC = NE + beam, ncp = (NC + 1) & ~1;
-    int ci[SLOTS], cr[SLOTS];                                                  // slot s = lane + 64 sl: extension (ci, cr), or stay of prefix ci (cr = -1), or nothing (ci = -1)
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-        const int s = lane + 64 * sl;
-        ci[sl] = -1; cr[sl] = -1;
-        if (s < NE) { int r = 0; while (off_s[r + 1] <= s) ++r; cr[sl] = r; ci[sl] = s - off_s[r]; }
-        else if (s < NC) ci[sl] = s - NE;
-    }
-    if (len > 0) {
+    if (tid < 4) live_s[tid] = 0;
+    if (tid < 64 * SL) rank_s[tid] = 0;
+    __syncthreads();
+    const int NE = off_s[K], nep = (NE + 7) & ~7, nblk = (nep + ((beam + 7) & ~7)) >> 3;      // (the key array is zero beyond the candidates)
+    int ci = -1, cr = -1, slot = 0;                                            // this thread's candidate: extension (ci, cr), or stay of prefix ci (cr = -1), or none
+    if (tid < NE) { int r = 0; while (off_s[r + 1] <= tid) ++r; cr = r; ci = tid - off_s[r]; slot = tid; }
+    else if (tid >= STAY0 && tid - STAY0 < beam) { ci = tid - STAY0; slot = nep + ci; }
+    // fold pairs: thread (q, g) compares phash[q] with hash[g + G u]: 16 lanes per q and one comparison for beam <= 16, else 8 lanes and four
+    const int G = beam <= 16 ? 16 : 8, fq = tid / G, fg = tid - fq * G, fn = beam <= 16 ? 1 : 4;
+    const unsigned ckey_addr = (unsigned)(unsigned long long)(lds_ptr_t)(&ckey[0]);
+    if (wave == 2 && len > 0) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        // frame 0 has landed
         if (lane == 0) spb[0] = reinterpret_cast<const float *>(&ring[0][0])[0];                 // tot (0) + lp[blank] of frame 0
-        fence();
     }
-
+    __syncthreads();
 #ifdef COCR_CHAIN_STAMPS_BUILD
     unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define BSTAMP(k) { const unsigned long long now = __builtin_readcyclecounter(); acc_t[k] += now - tprev; tprev = now; }
 #else
 #define BSTAMP(k)
 #endif
+
     for (int t = 0; t < len; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // (the ring slot of frame t - 1 is read no more)
-        request(t + 3);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        // frames <= t + 1 have landed (in-order completion)
-        BSTAMP(0)
+        if (wave == 2) {                                                       // (the ring slot of frame t - 1 was last read before barrier B of that frame)
+            request(t + 3);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                    // frames <= t + 1 have landed (in-order completion); the barriers publish that
+        }
         const unsigned char *cur = ring[t & (RING - 1)], *nxt = ring[(t + 1) & (RING - 1)];
         const float *lpn = reinterpret_cast<const float *>(nxt);
         const int32_t *tcc = reinterpret_cast<const int32_t *>(cur + COCR_BEAM_REC_TC);
         const float *tlc = reinterpret_cast<const float *>(cur + COCR_BEAM_REC_TL);
 
-        // candidates: keys to LDS; what a winner will need stays in registers
-        float n_pb[SLOTS], n_pnb[SLOTS], n_tot[SLOTS];
-        int n_last[SLOTS], n_bp[SLOTS], zero_slot = -1;
-        unsigned long long n_hash[SLOTS], n_ph[SLOTS];
-#pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) {
-            const int i = ci[sl], r = cr[sl];
-            unsigned long long key = 0ull;
-            n_pb[sl] = -INFINITY; n_pnb[sl] = -INFINITY; n_tot[sl] = -INFINITY; n_last[sl] = 0; n_bp[sl] = 0; n_hash[sl] = 0ull; n_ph[sl] = 0ull;
-            if (r >= 0) {                                                      // extension of prefix i by the class of rank r
-                const int c = tcc[r], li = last[i];
-                const float e = c > 0 ? (c == li ? pb[i] : tot[i]) + tlc[r] : -INFINITY;
-                key = beam_key(e, (unsigned)(i * C + c));
-                n_pnb[sl] = e; n_tot[sl] = e; n_last[sl] = c; n_bp[sl] = (i << 16) | c;
-                n_hash[sl] = hx[i] + (unsigned long long)(c + 1); n_ph[sl] = hash[i];
-            } else if (i >= 0) {                                               // prefix i stays; an extension equal to it folds into it
-                const int lq = last[i];
-                const unsigned long long ph = phash[i];
-                int iq = -1;
-                for (int j = 0; j < beam; ++j) if (hash[j] == ph && j != i) iq = j;
-                float mval = -INFINITY;
-                int mpos = 0x7fffffff;
-                if (lq > 0 && iq >= 0) {
-                    const float add = (lq == last[iq] ? pb[iq] : tot[iq]) + lpl[i];
-                    if (add > -INFINITY) {
-                        mval = add; mpos = iq * C + lq;
-                        const int r2 = cur[COCR_BEAM_REC_RK + lq];
-                        if (r2 < K && iq < off_s[r2 + 1] - off_s[r2]) zero_slot = off_s[r2] + iq;
-                    }
-                }
-                const float s_nb = lse2(spnb[i], mval), sc = lse2(spb[i], s_nb);
-                key = beam_key(sc, (unsigned)min(i * C, mpos));
-                n_pb[sl] = spb[i]; n_pnb[sl] = s_nb; n_tot[sl] = sc; n_last[sl] = lq; n_hash[sl] = hash[i]; n_ph[sl] = ph;
-                n_bp[sl] = mpos < i * C ? ((iq << 16) | lq) : (i << 16);      // first creator
+        // ---- fold pairs: prefix q equals prefix i extended by q's last label (then that extension adds to q's stay candidate)
+        {
+            const int lq = last[fq];
+            const unsigned long long ph = phash[fq];
+            int iq = -1;
+            for (int u = 0; u < fn; ++u) {
+                const int i = fg + G * u;
+                const bool hit = lq > 0 && i != fq && beam_eq64(hash[i], ph);
+                const unsigned grp = (unsigned)(__builtin_amdgcn_ballot_w64(hit) >> (lane & ~(G - 1))) & ((1u << G) - 1u);
+                if (grp) iq = G * u + (31 - __builtin_clz(grp));
             }
-            ckey[lane + 64 * sl] = key;
+            if (fg == 0) pair_s[fq] = iq >= 0 ? ((iq << 16) | lq) : -1;
         }
-        fence();
-        if (zero_slot >= 0) ckey[zero_slot] = 0ull;                            // folded: not a candidate of its own
-        fence();
+        // ---- the candidate: everything that does not depend on the pairs; what a survivor will need stays in registers
+        float n_pb = -INFINITY, n_pnb = -INFINITY, n_tot = -INFINITY, s_lpl = 0.f;
+        int n_last = 0, n_bp = 0;
+        unsigned long long n_hash = 0ull, n_ph = 0ull, key = 0ull;
+        if (cr >= 0) {                                                         // extension of prefix i by the class of rank r
+            const int i = ci, c = tcc[cr], li = last[i];
+            n_tot = c > 0 ? (c == li ? pb[i] : tot[i]) + tlc[cr] : -INFINITY;
+            n_hash = hx[i] + (unsigned long long)(c + 1); n_ph = hash[i];
+            n_last = c; n_bp = (i << 16) | c;
+        } else if (ci >= 0) {                                                  // prefix i stays
+            const int i = ci;
+            n_pb = spb[i]; n_pnb = spnb[i]; n_last = last[i]; n_hash = hash[i]; n_ph = phash[i]; s_lpl = lpl[i];
+        }
+        BSTAMP(0)
+        __syncthreads();                                                       // (A2)
+        if (cr >= 0) {
+            bool folded = false;                                               // it equals a live prefix: not a candidate of its own
+            int4 pr[SL == 2 ? 4 : 8];                                          // (SL == 2: beam <= 16; entries beyond the beam are -1; all reads first)
+#pragma unroll
+            for (int u = 0; u < (SL == 2 ? 4 : 8); ++u) pr[u] = *reinterpret_cast<const int4 *>(&pair_s[4 * u]);
+#pragma unroll
+            for (int u = 0; u < (SL == 2 ? 4 : 8); ++u) folded |= (pr[u].x == n_bp) | (pr[u].y == n_bp) | (pr[u].z == n_bp) | (pr[u].w == n_bp);
+            if (folded) n_tot = -INFINITY;
+            key = beam_key(n_tot, (unsigned)(ci * C + n_last));
+            n_pnb = n_tot;
+        } else if (ci >= 0) {
+            const int i = ci, pr = pair_s[i];
+            float mval = -INFINITY;
+            int mpos = 0x7fffffff;
+            if (pr >= 0) {
+                const int iq = pr >> 16;
+                const float add = (n_last == last[iq] ? pb[iq] : tot[iq]) + s_lpl;
+                if (add > -INFINITY) { mval = add; mpos = iq * C + n_last; }
+            }
+            n_pnb = lse2(n_pnb, mval);
+            n_tot = lse2(n_pb, n_pnb);
+            key = beam_key(n_tot, (unsigned)min(i * C, mpos));
+            n_bp = mpos < i * C ? pr : (i << 16);                              // first creator
+        }
+        if (ci >= 0) ckey[slot] = key;
+        {
+            const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(key != 0ull));
+            if (lane == 0) live_s[wave] = cnt;
+        }
         BSTAMP(1)
-        // ranks: the number of larger keys
-        unsigned long long k[SLOTS];
-        int rank[SLOTS], nlive = 0;
+        __syncthreads();                                                       // (B)
+        // ---- rank = the number of larger keys.  Every wave takes a quarter of the key blocks (eight keys each) for ALL candidates
+        // (lane l: candidates l, l + 64, ...): all 256 threads reading all keys would be 180 KB per frame through the LDS port.
+        {
+            unsigned long long k[SL];
+            int rk[SL], rk2[SL];
 #pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) { k[sl] = ckey[lane + 64 * sl]; rank[sl] = 0; nlive += __builtin_popcountll(__builtin_amdgcn_ballot_w64(k[sl] != 0ull)); }
-#pragma unroll 4
-        for (int j = 0; j < ncp; j += 2) {
-            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(&ckey[j]);
+            for (int sl = 0; sl < SL; ++sl) { k[sl] = ckey[lane + 64 * sl]; rk[sl] = 0; rk2[sl] = 0; }
+            beam_u64x2 ka[4], kb[4];
+            int b = wave;
+            if (b < nblk) {
 #pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) rank[sl] += (kk.x > k[sl]) + (kk.y > k[sl]);
-        }
-        const int nsel = min(beam, nlive);
-        fence();
-        BSTAMP(2)
-        // the survivors write next frame's prefixes
-        const float lp0n = lpn[0];
-#pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) {
-            const int R = rank[sl];
-            if (k[sl] != 0ull && R < beam) {
-                const int nl = n_last[sl];
-                const float l2 = lpn[nl];
-                pb[R] = n_pb[sl]; tot[R] = n_tot[sl]; last[R] = nl; hash[R] = n_hash[sl]; phash[R] = n_ph[sl]; hx[R] = n_hash[sl] * PRIME;
-                spb[R] = n_tot[sl] + lp0n; spnb[R] = nl > 0 ? n_pnb[sl] + l2 : -INFINITY; lpl[R] = nl > 0 ? l2 : 0.f;
-                if (bp_in_lds) bpl[t * beam + R] = n_bp[sl]; else bpg[(size_t)t * NB + R] = n_bp[sl];
+                for (int u = 0; u < 4; ++u) ka[u] = *reinterpret_cast<const beam_u64x2 *>(&ckey[8 * b + 2 * u]);
             }
+            for (; b + 4 < nblk; b += 8) {                                     // (two steps per trip: the key registers alternate)
+                beam_rank_step<true>(rk[0], rk2[0], kb, ka, k[0], ckey_addr + (b + 4) * 64);
+#pragma unroll
+                for (int sl = 1; sl < SL; ++sl) beam_rank_step<false>(rk[sl], rk2[sl], kb, ka, k[sl], 0u);
+                if (b + 8 < nblk) {
+                    beam_rank_step<true>(rk[0], rk2[0], ka, kb, k[0], ckey_addr + (b + 8) * 64);
+#pragma unroll
+                    for (int sl = 1; sl < SL; ++sl) beam_rank_step<false>(rk[sl], rk2[sl], ka, kb, k[sl], 0u);
+                } else {
+#pragma unroll
+                    for (int sl = 0; sl < SL; ++sl) beam_rank_step<false>(rk[sl], rk2[sl], ka, kb, k[sl], 0u);
+                    b = nblk;                                                  // done
+                }
+            }
+            if (b < nblk) {
+#pragma unroll
+                for (int sl = 0; sl < SL; ++sl) beam_rank_step<false>(rk[sl], rk2[sl], kb, ka, k[sl], 0u);
+            }
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl) atomicAdd(&rank_s[lane + 64 * sl], rk[sl] + rk2[sl]);
         }
-        if (lane >= nsel && lane < beam) {                                     // fewer candidates than the beam holds
-            pb[lane] = -INFINITY; tot[lane] = -INFINITY; spb[lane] = -INFINITY; spnb[lane] = -INFINITY; lpl[lane] = 0.f;
-            last[lane] = 0; hash[lane] = 0ull; phash[lane] = 0ull; hx[lane] = 0ull;
+        __syncthreads();                                                       // (C)
+        int rank = 0;
+        if (ci >= 0) { rank = rank_s[slot]; rank_s[slot] = 0; }
+        const int4 lv = *reinterpret_cast<const int4 *>(live_s);
+        const int nsel = min(beam, lv.x + lv.y + lv.z + lv.w);
+        BSTAMP(2)
+        // ---- the survivors write next frame's prefixes
+        if (key != 0ull && rank < beam) {
+            const int R = rank, nl = n_last;
+            const float l2 = lpn[nl], lp0n = lpn[0];
+            pb[R] = n_pb; tot[R] = n_tot; last[R] = nl; hash[R] = n_hash; phash[R] = n_ph; hx[R] = n_hash * PRIME;
+            spb[R] = n_tot + lp0n; spnb[R] = nl > 0 ? n_pnb + l2 : -INFINITY; lpl[R] = nl > 0 ? l2 : 0.f;
+            if (bp_in_lds) bpl[t * beam + R] = n_bp; else bpg[(size_t)t * NB + R] = n_bp;
         }
-        fence();
+        if (tid >= nsel && tid < beam) {                                       // fewer candidates than the beam holds
+            pb[tid] = -INFINITY; tot[tid] = -INFINITY; spb[tid] = -INFINITY; spnb[tid] = -INFINITY; lpl[tid] = 0.f;
+            last[tid] = 0; hash[tid] = 0ull; phash[tid] = 0ull; hx[tid] = 0ull;
+        }
         BSTAMP(3)
+        __syncthreads();                                                       // (A)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     // ---- best prefix: walk the back-pointers (one lane), then ends / confidences in parallel over the labels
     int32_t *olab = labels + (size_t)n * max_per_line, *ost = starts + (size_t)n * max_per_line;
     if (bp_in_lds) {
         int32_t *stk = bpl + (size_t)T * beam;                                 // [T][2] (label, frame), last label first
-        if (lane == 0) {
+        if (tid == 0) {
             int cnt = 0, e = 0;
             for (int t = len - 1; t >= 0; --t) {
                 const int v = bpl[t * beam + e];
@@ -478,10 +553,10 @@ __global__ __launch_bounds__(64) void ctc_beam_walk_kernel(const float *__restri
             s_cnt = cnt;
             counts[n] = cnt;
         }
-        fence();
+        __syncthreads();
         const int cnt = s_cnt;
-        for (int k2 = lane; k2 < min(cnt, max_per_line); k2 += 64) { olab[k2] = stk[2 * (cnt - 1 - k2)]; ost[k2] = stk[2 * (cnt - 1 - k2) + 1]; }
-    } else if (lane == 0) {
+        for (int k2 = tid; k2 < min(cnt, max_per_line); k2 += 256) { olab[k2] = stk[2 * (cnt - 1 - k2)]; ost[k2] = stk[2 * (cnt - 1 - k2) + 1]; }
+    } else if (tid == 0) {
         int cnt = 0, e = 0;
         for (int t = len - 1; t >= 0; --t) {
             const int v = bpg[(size_t)t * NB + e];
@@ -499,10 +574,9 @@ __global__ __launch_bounds__(64) void ctc_beam_walk_kernel(const float *__restri
         counts[n] = cnt;
     }
     __threadfence_block();
-    fence();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     const int cnt = min(s_cnt, max_per_line);
-    for (int k2 = lane; k2 < cnt; k2 += 64) {
+    for (int k2 = tid; k2 < cnt; k2 += 256) {
         const int c = olab[k2], s0 = ost[k2], limit = k2 + 1 < cnt ? ost[k2 + 1] : len;
         int e = s0;
         while (e + 1 < limit && lg[(size_t)(e + 1) * C + c] > lg[(size_t)(e + 1) * C]) ++e;
@@ -513,6 +587,6 @@ __global__ __launch_bounds__(64) void ctc_beam_walk_kernel(const float *__restri
     }
 #ifdef COCR_CHAIN_STAMPS_BUILD
     BSTAMP(4)
-    if (dbg && n == 0 && lane == 0) for (int k2 = 0; k2 < 5; ++k2) dbg[k2] = acc_t[k2] + 1;
+    if (dbg && n == 0 && (tid == STAY0 || tid == 0)) for (int k2 = 0; k2 < 5; ++k2) dbg[(tid ? 0 : 5) + k2] = acc_t[k2] + 1;
 #endif
 }
