@@ -127,24 +127,29 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     const int prow = heads * DHP;
     const T *pbase = ptab + hh * DHP;
 
-    // tile loads: K/V rows j0 .. j0+63 (clamped), band rows B0 .. B0+127 (clamped), B0 = CEN - (i0b + 63) + j0
+    // tile loads: K/V rows j0 .. j0+63, band rows B0 .. B0+127, B0 = CEN - (i0b + 63) + j0.  No clamps: q / k / v hold Tp rows per
+    // (line, head) with Tp a multiple of 64 (rows beyond T are zero and masked in the last tile), and the band stays inside the table
+    // for T <= 4900 (cocr_forward refuses longer lines).  Each lane's byte offsets inside a tile are constants; the tile bases are
+    // uniform, so a tile costs its 8 load instructions and two scalar adds (the clamped per-row addresses were ~40 vector
+    // instructions per tile in a loop whose SIMDs are issue-bound).
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 rk[KV_IT], rv[KV_IT], rp[P_IT];
+    unsigned kvoff[KV_IT], poff[P_IT];
+#pragma unroll
+    for (int it = 0; it < KV_IT; ++it) { const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR; kvoff[it] = (unsigned)row * RB + ch * 16; }
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) { const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR; poff[it] = (unsigned)row * (unsigned)prow * (unsigned)sizeof(T) + ch * 16; }
     auto load_tile = [&](int j0) {
-        const int B0 = COCR_POS_CENTER - (i0b + 63) + j0;
+        const unsigned char *kt = reinterpret_cast<const unsigned char *>(kbase) + (size_t)j0 * RB;
+        const unsigned char *vt = reinterpret_cast<const unsigned char *>(vbase) + (size_t)j0 * RB;
+        const unsigned char *pt = reinterpret_cast<const unsigned char *>(pbase) + (size_t)(COCR_POS_CENTER - (i0b + 63) + j0) * prow * sizeof(T);
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {
-            const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
-            const unsigned off = (unsigned)min(j0 + row, Tn - 1) * DHP + ch * (16 / (int)sizeof(T));      // 32-bit offset from a uniform base
-            rk[it] = *reinterpret_cast<const u32x4 *>(kbase + off);
-            rv[it] = *reinterpret_cast<const u32x4 *>(vbase + off);
+            rk[it] = *reinterpret_cast<const u32x4 *>(kt + kvoff[it]);
+            rv[it] = *reinterpret_cast<const u32x4 *>(vt + kvoff[it]);
         }
 #pragma unroll
-        for (int it = 0; it < P_IT; ++it) {
-            const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
-            const int pr = min(max(B0 + row, 0), COCR_POS_ROWS - 1);
-            rp[it] = *reinterpret_cast<const u32x4 *>(pbase + ((unsigned)pr * (unsigned)prow + ch * (16 / (int)sizeof(T))));
-        }
+        for (int it = 0; it < P_IT; ++it) rp[it] = *reinterpret_cast<const u32x4 *>(pt + poff[it]);
     };
     auto store_tile = [&]() {
 #pragma unroll

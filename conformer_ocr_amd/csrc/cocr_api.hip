@@ -641,7 +641,7 @@ extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
     int T = W;
     for (int i = 0; i < m->snum; ++i) T = out_len1(T);
     int T2 = out_len1(out_len1(W));                 // frames after the fused first two stages
-    const size_t M = (size_t)N * T, Tp = round_up(T, 32);
+    const size_t M = (size_t)N * T, Tp = round_up(T, 64);      // q / k / v rows per (line, head): whole 64-key tiles (attention.hip.h reads them unclamped)
     int rc;
     const size_t zbytes = (size_t)N * T2 * m->feats[1] * m->C * es;
     if ((rc = ws_alloc(m, &m->z_a, zbytes))) return rc;
@@ -836,7 +836,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         }
         Tc = To; Fc = Fo;
     }
-    const int Tn = Tc, F = Fc, M = N * Tn, Tp = round_up(Tn, 32);
+    const int Tn = Tc, F = Fc, M = N * Tn, Tp = round_up(Tn, 64);
     float *x = m->x;
     T *xn = (T *)m->xn, *hid = (T *)m->hid, *q = (T *)m->q, *k = (T *)m->k, *v = (T *)m->vt, *ctx = (T *)m->ctx, *glu = (T *)m->glu,
       *dwo = (T *)m->dwo;

@@ -36,7 +36,7 @@ def hip_tap(eng, name, hp, N, T):
     """A debug tap in the oracle's layout."""
     a = eng.tap(name)
     h, dh = hp.num_attention_heads, hp.d_head
-    dhp, Tp = -(-dh // 32) * 32, -(-T // 32) * 32
+    dhp, Tp = -(-dh // 32) * 32, -(-T // 64) * 64
     kind = name.split('.')[-1]
     if kind in ('q', 'k', 'v'):
         return a[:N * h * Tp * dhp].reshape(N, h, Tp, dhp)[:, :, :T, :dh].transpose(0, 2, 1, 3)
