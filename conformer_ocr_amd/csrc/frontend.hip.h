@@ -54,15 +54,16 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
                                                          const bf16_t *__restrict__ w0f, const float *__restrict__ b0,
                                                          const bf16_t *__restrict__ dwf, const float *__restrict__ b2,
                                                          const bf16_t *__restrict__ wpw,        // fragment-major (256, 256)
-                                                         const float *__restrict__ bpw, bf16_t *__restrict__ Z3, int HS, unsigned long long *stamps) {
+                                                         const float *__restrict__ bpw, bf16_t *__restrict__ Z3, int HS, int N, unsigned long long *stamps) {
     typedef bf16_t T;
     constexpr int C = 256, F = 24, TB = 4, BMC = TB * F, MT = 6, KC1 = C / 32;
     constexpr int NA = 2 * TB + 1, NCOL = 4 * TB + 4, ZR = 2 * F + 2, ZC = 72;      // Z1 tile: rows zr = f1 + 1 in [0, 2F + 1], 64 channels + pad
     constexpr int PANEL = BMC * 128, IMG = 4 * PANEL, OS = C * 2 + 16, SLICE = 16 * 512;
+    constexpr int XAB = BMC * OS > IMG ? BMC * OS : IMG;                  // the operand image's area also takes the bf16 output tile [96][OS]
     static_assert(BMC == 96, "operand image of the chain kernels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *xa = smem;                                             // 96 x 256 bf16 operand image (Z2)
-    T *z1 = reinterpret_cast<T *>(smem + IMG);                            // [NA][ZR][ZC]; later the bf16 output tile [96][OS]
+    T *z1 = reinterpret_cast<T *>(smem + XAB);                            // [NA][ZR][ZC]
     T *xs = z1 + (NA * ZR + 1) * ZC;                                      // (one dump row behind the Z1 tile) [NCOL][HS] transposed line tile: row rr <-> image row rr - 1
     unsigned char *prm = reinterpret_cast<unsigned char *>(xs + NCOL * HS);   // conv.0 A-fragments (8 KiB), b0 (1 KiB), b2 (1 KiB); 16-byte aligned (HS % 4 == 0)
     const T *w0s = reinterpret_cast<const T *>(prm);
@@ -71,12 +72,16 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4, swz = r16 & 7;
-    const int b = blockIdx.y, t0 = blockIdx.x * TB;
-    const int col0 = 4 * t0 - 3;
+    // PERSISTENT: one workgroup per CU walks the (line, 4-frame block) items blockIdx.x, blockIdx.x + gridDim.x, ...  With one workgroup
+    // per CU nothing else hides an item's input latency (a 20-column strip of the line: 96 short row segments from HBM, ~3 us of the
+    // ~14 us an item took when every item was a workgroup of its own), so the NEXT item's pixels are requested during the last
+    // channel pass of the current one and wait in 4 registers per thread; the parameters go to LDS once.
+    const int nblk = (Tn + TB - 1) / TB, nitems = nblk * N, stride = gridDim.x;
+    int item = blockIdx.x;
 #ifdef COCR_CHAIN_STAMPS_BUILD
     int nstamp = 0;
     auto stamp = [&]() {
-        if (stamps && blockIdx.x == 1 && blockIdx.y == 0 && tid == 0) stamps[nstamp] = __builtin_readcyclecounter();
+        if (stamps && blockIdx.x == 1 && tid == 0 && nstamp < 40) stamps[nstamp] = __builtin_readcyclecounter();
         ++nstamp;
     };
 #else
@@ -85,46 +90,52 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
     stamp();
 
     // ---- line tile (transposed, bf16, zero outside the image): lanes run along the image row (coalesced), all of a thread's
-    // loads are issued before the first use; requested BEFORE the weight ring (loads return in order)
-    const TIn *Xb = X + (size_t)b * H * W;
+    // loads are issued before the first use
     constexpr int FILL = 4;                                 // NCOL * HS <= 4 * 512 (HS <= 100: checked by the launcher)
-    float fv[FILL];
+    TIn fv[FILL];                                           // raw pixels (converted and masked when they are written to LDS: no use, no wait, here)
+    auto load_pixels = [&](int it) {
+        const int bb = it / nblk, c0 = 4 * (it - bb * nblk) * TB - 3;
+        const TIn *Xb = X + (size_t)bb * H * W;
+        int tv = tid;
+        asm volatile("" : "+v"(tv));                        // (index arithmetic recomputed per item: hoisted out of the item loop it costs registers the pointwise stage needs)
 #pragma unroll
-    for (int u = 0; u < FILL; ++u) {
-        const int i = tid + 512 * u, rr = i / NCOL, ci = i - rr * NCOL;
-        const int w = min(max(col0 + ci, 0), W - 1), r = min(max(rr - 1, 0), H - 1);      // clamped address + select
-        const float v = pixel_to_f32<TIn>(Xb[(size_t)r * W + w]);
-        fv[u] = (col0 + ci >= 0 && col0 + ci < W && rr >= 1 && rr <= H) ? v : 0.0f;
-    }
-    // ---- conv.0 fragments and the two bias vectors -> LDS (10 wave-instructions of 1 KiB, asynchronous)
+        for (int u = 0; u < FILL; ++u) {
+            const int i = tv + 512 * u, rr = i / NCOL, ci = i - rr * NCOL;
+            const int w = min(max(c0 + ci, 0), W - 1), r = min(max(rr - 1, 0), H - 1);      // clamped address; the select is made at the write
+            fv[u] = Xb[(size_t)r * W + w];
+        }
+    };
+    if (item < nitems) load_pixels(item);
+    // ---- conv.0 fragments and the two bias vectors -> LDS (10 wave-instructions of 1 KiB), once
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w0f + wave * 512 + lane * 8), (lds_ptr_t)(prm + wave * 1024), 16, 0, 0);
     if (wave < 2) __builtin_amdgcn_global_load_lds((gbl_ptr_t)((wave ? b2 : b0) + lane * 4), (lds_ptr_t)(prm + 8192 + wave * 1024), 16, 0, 0);
-    // ---- pointwise-conv weight ring: consumed last
-    bf16x8 ring[16];
-    {
-        const T *first = wpw + (size_t)wave * SLICE;
-#pragma unroll
-        for (int f = 0; f < 16; ++f) ring[f] = *reinterpret_cast<const bf16x8 *>(first + f * 512 + lane * 8);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int FT = (F1 + 15) >> 4, ntile = NA * FT;        // 16-pixel tiles of the Z1 columns
+    // depthwise work of this wave in every pass: channel block blk of the pass, position tiles mq, mq + 2, mq + 4
+    const int blk = wave & 3, mq = wave >> 2;
+
+    for (; item < nitems; item += stride) {
+    const int b = item / nblk, t0 = (item - b * nblk) * TB;
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    bf16x8 ring[16];                                       // pointwise-conv weights of this wave's 32 output channels: requested in the last pass
     // the Z1 tile's zero rows (the depthwise conv's padding)
-    for (int i = tid; i < NA * ZC; i += 512) {
+    for (int i = tv; i < NA * ZC; i += 512) {
         const int a = i / ZC, c = i - a * ZC;
         z1[(a * ZR) * ZC + c] = (T)0.0f;
         for (int zr = F1 + 1; zr < ZR; ++zr) z1[(a * ZR + zr) * ZC + c] = (T)0.0f;
     }
 #pragma unroll
     for (int u = 0; u < FILL; ++u) {
-        const int i = tid + 512 * u, rr = i / NCOL, ci = i - rr * NCOL;
-        if (i < NCOL * HS) xs[ci * HS + rr] = (T)fv[u];
+        const int i = tv + 512 * u, rr = i / NCOL, ci = i - rr * NCOL, c = 4 * t0 - 3 + ci;
+        const bool inside = c >= 0 && c < W && rr >= 1 && rr <= H;
+        if (i < NCOL * HS) xs[ci * HS + rr] = (T)(inside ? pixel_to_f32<TIn>(fv[u]) : 0.0f);
     }
     stamp();
-    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");         // parameter DMAs landed (older than the 16 ring loads, which stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     stamp();
 
-    const int FT = (F1 + 15) >> 4, ntile = NA * FT;        // 16-pixel tiles of the Z1 columns
-    // depthwise work of this wave in every pass: channel block blk of the pass, position tiles mq, mq + 2, mq + 4
-    const int blk = wave & 3, mq = wave >> 2;
     // conv.0 work of this wave in every pass: pixel tiles wave, wave + 8, ... (at most 4) x the pass's 4 channel tiles; the pixel
     // fragments do not depend on the pass
     s16x4 pf[4];
@@ -149,8 +160,7 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
         for (int ch = 0; ch < 5; ++ch) dwn[ch] = *reinterpret_cast<const bf16x8 *>(dwf + ((size_t)(4 * pass + blk) * 5 + ch) * 512 + lane * 8);
     };
     request_dw(0);
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
+    auto do_pass = [&](int pass, auto LAST) {
         const int cb = 64 * pass;
         bf16x8 dwb[5];
 #pragma unroll
@@ -184,6 +194,14 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
                 }
         };
         if (all_valid) z1_epilogue(std::false_type{}); else z1_epilogue(std::true_type{});
+        if constexpr (decltype(LAST)::value) {
+            // the conv.0 accumulators are dead: the pointwise weights (used after this pass) and, behind them (loads return in order), the
+            // next item's pixels
+            const T *first = wpw + (size_t)wave * SLICE;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) ring[f] = *reinterpret_cast<const bf16x8 *>(first + f * 512 + lane * 8);
+            if (item + stride < nitems) load_pixels(item + stride);
+        }
         stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -206,7 +224,10 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
         stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // Z1 tile free for the next pass; after the last pass the operand image is complete
-    }
+    };
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) do_pass(pass, std::false_type{});
+    do_pass(3, std::true_type{});                          // (a copy of its own: the weight ring is live only from here on)
 
     // ---- pointwise conv.3 + ReLU: one step of the chain product, this wave's 32 output channels
     const f32x4 bp0 = *reinterpret_cast<const f32x4 *>(bpw + 32 * wave + 4 * g), bp1 = *reinterpret_cast<const f32x4 *>(bpw + 32 * wave + 16 + 4 * g);
@@ -224,7 +245,11 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
             for (int i = 0; i < MT; ++i) acc[i][j] = mma16(ring[2 * kk + j], a[i], acc[i][j]);
     }
     stamp();
-    unsigned char *tile = reinterpret_cast<unsigned char *>(z1);          // bf16 [96][OS]: the Z1 tile is dead
+    // The output tile takes the operand image's place (every wave has read its last fragment of it: one barrier), NOT the Z1 tile's:
+    // the next item's line tile, zero rows and conv.0 passes then start while this item's rows are still being copied out, and the
+    // item needs no closing barrier (the image is next written by the depthwise stage of the next item, two barriers on).
+    __builtin_amdgcn_s_barrier();
+    unsigned char *tile = xa;                                             // bf16 [96][OS]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -238,11 +263,12 @@ __global__ __launch_bounds__(512) void frontend96_kernel(const TIn *__restrict__
     stamp();
     // rows (frame tl, f) of this line are consecutive rows of the (B*T*F, C) output: coalesced 16-byte stores
     T *out = Z3 + ((size_t)b * Tn + t0) * F * C;
-    for (int id = tid; id < BMC * 32; id += 512) {
+    for (int id = tv; id < BMC * 32; id += 512) {
         const int row = id >> 5, ch = id & 31;
         if (t0 + row / F < Tn) copy16(out + (size_t)row * C + ch * 8, reinterpret_cast<const T *>(tile + row * OS + ch * 16));
     }
     stamp();
+    }
 }
 
 static inline bool frontend96_supported(int C, int F1, int F2, int H) { return C == 256 && F2 == 24 && F1 <= 2 * F2 && H <= 4 * F2; }
@@ -252,10 +278,18 @@ static inline hipError_t launch_frontend96(hipStream_t s, const TIn *X, int N, i
                                            const bf16_t *dwf, const float *b2, const bf16_t *wpw, const float *bpw, bf16_t *Z3, unsigned long long *stamps = nullptr) {
     const int FT = (F1 + 15) / 16, HS = 2 * 16 * FT + 4;
     const size_t z1b = (size_t)(9 * 50 + 1) * 72 * 2, tileb = (size_t)96 * (256 * 2 + 16);
-    const size_t lds = (size_t)4 * 96 * 128 + std::max(z1b, tileb) + (size_t)20 * HS * 2 + 10240;
+    const size_t lds = std::max((size_t)4 * 96 * 128, tileb) + z1b + (size_t)20 * HS * 2 + 10240;
     auto kern = frontend96_kernel<TIn>;
     hipError_t e = raise_lds_limit((const void *)kern, lds + 4096);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((Tn + 3) / 4, N), dim3(512), lds, s, X, H, W, T1, F1, Tn, w0f, b0, dwf, b2, wpw, bpw, Z3, HS, stamps);
+    static int ncu = 0;                                    // one persistent workgroup per CU (the kernel's LDS allows no second one)
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int nitems = ((Tn + 3) / 4) * N;
+    hipLaunchKernelGGL(kern, dim3(std::min(nitems, ncu)), dim3(512), lds, s, X, H, W, T1, F1, Tn, w0f, b0, dwf, b2, wpw, bpw, Z3, HS, N, stamps);
     return hipGetLastError();
 }
