@@ -26,6 +26,35 @@ template <typename TIn> __device__ __forceinline__ float pixel_to_f32(TIn v);
 template <> __device__ __forceinline__ float pixel_to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float pixel_to_f32<uint8_t>(uint8_t v) { return (float)v / 255.0f; }
 
+// ---- frontend of subsampling_factor 2: conv.0 + ReLU only (convolution.py:192-198; no depthwise / pointwise stage follows) --------
+//   Z1[b][t1][f1][c] = relu(b0[c] + sum_{dt,df} w0[c][dt][df] X[b][2 f1 + df - 1][2 t1 + dt - 1])      channel-last, like Z3 elsewhere
+// One thread per (position, channel pair); a workgroup's 256 threads cover 512 / C positions.  HBM-bound on its output
+// (N T1 F1 C elements against N H W pixels read); not a measured configuration (no reference hyper-parameter set uses factor 2).
+template <typename T, typename TIn>
+__global__ __launch_bounds__(256) void frontend_conv0_kernel(const TIn *__restrict__ X, int H, int W, int T1, int F1, int C, size_t npos,
+                                                             const float *__restrict__ w0, const float *__restrict__ b0, T *__restrict__ Z1) {
+    const int C2 = C >> 1;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t pos = idx / C2;
+    if (pos >= npos) return;
+    const int c = 2 * (int)(idx - pos * C2);
+    const int f1 = (int)(pos % F1), t1 = (int)((pos / F1) % T1);
+    const size_t b = pos / ((size_t)F1 * T1);
+    const TIn *Xb = X + b * H * W;
+    f32x2 acc = {b0[c], b0[c + 1]};
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int df = 0; df < 3; ++df) {
+            const int w = 2 * t1 + dt - 1, r = 2 * f1 + df - 1;
+            const float v = (w >= 0 && w < W && r >= 0 && r < H) ? pixel_to_f32<TIn>(Xb[(size_t)min(max(r, 0), H - 1) * W + min(max(w, 0), W - 1)]) : 0.0f;
+            acc[0] = fmaf(w0[c * 9 + 3 * dt + df], v, acc[0]);
+            acc[1] = fmaf(w0[(c + 1) * 9 + 3 * dt + df], v, acc[1]);
+        }
+    typedef typename Pair<T>::type P2;
+    *reinterpret_cast<P2 *>(Z1 + pos * C + c) = (P2){(T)fmaxf(acc[0], 0.f), (T)fmaxf(acc[1], 0.f)};
+}
+
 template <typename T, typename TIn>
 __global__ __launch_bounds__(256) void frontend_conv12_kernel(const TIn *__restrict__ X, int H, int W, int T1, int F1, int Tn, int F, int C,
                                                               const float *__restrict__ w0, const float *__restrict__ b0,

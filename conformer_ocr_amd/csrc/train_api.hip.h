@@ -38,6 +38,7 @@ static bool train_is_buffer(const std::string &n) { return n.find("running_mean"
 
 extern "C" int cocr_train_begin(cocr_model *m) {
     if (!m) return fail(COCR_EINVAL, "null argument");
+    if (m->snum < 2) return fail(COCR_EUNSUPPORTED, "the training step covers subsampling_factor >= 4 (factor 2 has no depthwise / pointwise stage)");
     HIP_TRY(hipSetDevice(m->device));
     train_free(m);
     TrainState *t = new TrainState();

@@ -249,6 +249,13 @@ def text_cases(meta):
     run_text_case(meta, 'cfg4_text', synth.hparams('cfg4'), 2004, widths, 8, 200)
 
 
+def tiny2_case(meta):
+    """tiny2: subsampling_factor 2 (conv.0 + ReLU, then the output linear: convolution.py:182-215 with one sampling stage)."""
+    hp2 = synth.hparams('tiny', subsampling_factor=2)
+    _, enc2, _ = run_case(meta, 'tiny2', hp2, 1239, 3, 48, widths=[48, 31, 40])
+    meta['tiny2']['encoder_state_keys'] = [(k, list(v.shape), str(v.dtype)) for k, v in enc2.state_dict().items()]
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -256,6 +263,13 @@ def main():
         with open(os.path.join(HERE, 'meta.json')) as fp:
             meta = json.load(fp)
         text_cases(meta)
+        with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
+            json.dump(meta, fp, indent=1)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'tiny2':      # only the factor-2 fixture, merged into the existing meta.json
+        with open(os.path.join(HERE, 'meta.json')) as fp:
+            meta = json.load(fp)
+        tiny2_case(meta)
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
@@ -268,6 +282,7 @@ def main():
     hp8 = synth.hparams('tiny', subsampling_factor=8, height=32)
     _, enc8, _ = run_case(meta, 'tiny8', hp8, 1235, 2, 96, widths=[96, 61])
     meta['tiny8']['encoder_state_keys'] = [(k, list(v.shape), str(v.dtype)) for k, v in enc8.state_dict().items()]
+    tiny2_case(meta)
     # cfg1: default_specs.py verbatim, BASELINE configs[0]: 4 lines 96x512 (lens 512,400,300,512)
     hp1 = synth.hparams('cfg1')
     _, enc1, _ = run_case(meta, 'cfg1', hp1, 1235, 4, 512, widths=[512, 400, 300, 512])

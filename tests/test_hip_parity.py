@@ -75,7 +75,7 @@ def _check_case(case, name, dtype, n=None):
     return dev, mism, eng, logits, out_lens
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny8', 'cfg1', 'cfg2_ragged', 'cfg4'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny2', 'tiny8', 'cfg1', 'cfg2_ragged', 'cfg4'])
 def test_fp32_logits_within_1e3(case, name):
     dev, mism, *_ = _check_case(case, name, 'fp32')
     assert dev <= FP32_TOL and mism == 0
@@ -87,7 +87,7 @@ def test_fp32_cfg2_full_batch(case):
     assert dev <= FP32_TOL and mism == 0
 
 
-@pytest.mark.parametrize('name', ['tiny', 'cfg1', 'cfg2', 'cfg2_ragged', 'cfg4'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny2', 'cfg1', 'cfg2', 'cfg2_ragged', 'cfg4'])
 def test_bf16_labels_identical_outside_margin(case, name):
     dev, mism, *_ = _check_case(case, name, 'bf16')
     assert mism == 0

@@ -10,7 +10,7 @@ from oracle.conformer_ref import Oracle, out_len as oracle_out_len
 TOL = 1e-4   # fp32 restatement vs fp32 reference, abs on logits of magnitude ~10 (measured <= 3e-5)
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny8', 'cfg1'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny2', 'tiny8', 'cfg1'])
 def test_oracle_matches_reference_logits(case, name):
     hp, state, image, lens, g = case(name)
     o = Oracle(hp, state, torch.float32)
@@ -55,7 +55,7 @@ def test_padding_leak_is_reproduced(case):
 
 
 def test_state_dict_key_map_matches_reference(golden_meta):
-    for name in ('tiny', 'tiny8'):
+    for name in ('tiny', 'tiny2', 'tiny8'):
         m = golden_meta[name]
         spec = encoder_state_spec(HParams(**m['hparams']))
         assert [(k, list(v[0])) for k, v in spec.items()] == [(k, s) for k, s, _ in m['encoder_state_keys']]
