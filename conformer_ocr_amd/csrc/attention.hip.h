@@ -38,8 +38,7 @@ __device__ __forceinline__ float max3_f(float a, float b, float c) {
     return r;
 }
 
-#define COCR_POS_CENTER 4999
-#define COCR_POS_ROWS 9999
+#define COCR_POS_MAXLEN 5000        // the reference's RelPositionalEncoding(max_len): 2 * max_len - 1 table rows, row max_len - 1 <-> relative position 0
 
 // V^T fragment of one k-chunk (32 keys) for head-dim row tile d: element e of quad g <-> key 16 (e>>2) + 4g + (e&3)
 // (the same permutation the exponentiated scores have in their accumulator registers).
@@ -70,7 +69,7 @@ template <typename T, int DHP>   // DHP = padded head dim, multiple of 32
 __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
                                                                const T *__restrict__ ptab, const float *__restrict__ ub,
                                                                const float *__restrict__ vb, T *__restrict__ ctx,
-                                                               int Tn, int Tp, int heads, int dh, float scale, unsigned long long *stamps) {
+                                                               int Tn, int Tp, int heads, int dh, float scale, int pos_center, unsigned long long *stamps) {
     constexpr int KC = DHP / 32;                      // k-chunks over the head dim
     constexpr bool MERGE = sizeof(T) == 2 && DHP <= 64;   // one softmax step per 64 keys (bf16: the registers allow it at 3 waves per SIMD)
     constexpr int DT = DHP / 16;                      // 16-row tiles of O^T
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 
     // tile loads: K/V rows j0 .. j0+63, band rows B0 .. B0+127, B0 = CEN - (i0b + 63) + j0.  No clamps: q / k / v hold Tp rows per
     // (line, head) with Tp a multiple of 64 (rows beyond T are zero and masked in the last tile), and the band stays inside the table
-    // for T <= 4900 (cocr_forward refuses longer lines).  Each lane's byte offsets inside a tile are constants; the tile bases are
+    // (cocr_forward rebuilds the tables for a line longer than they cover).  Each lane's byte offsets inside a tile are constants; the tile bases are
     // uniform, so a tile costs its 8 load instructions and two scalar adds (the clamped per-row addresses were ~40 vector
     // instructions per tile in a loop whose SIMDs are issue-bound).
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     auto load_tile = [&](int j0) {
         const unsigned char *kt = reinterpret_cast<const unsigned char *>(kbase) + (size_t)j0 * RB;
         const unsigned char *vt = reinterpret_cast<const unsigned char *>(vbase) + (size_t)j0 * RB;
-        const unsigned char *pt = reinterpret_cast<const unsigned char *>(pbase) + (size_t)(COCR_POS_CENTER - (i0b + 63) + j0) * prow * sizeof(T);
+        const unsigned char *pt = reinterpret_cast<const unsigned char *>(pbase) + (size_t)(pos_center - (i0b + 63) + j0) * prow * sizeof(T);
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {
             rk[it] = *reinterpret_cast<const u32x4 *>(kt + kvoff[it]);

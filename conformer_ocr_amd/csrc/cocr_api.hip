@@ -114,6 +114,7 @@ struct cocr_model {
     void *xn = nullptr, *hid = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *glu = nullptr, *dwo = nullptr;
     size_t qkv_bytes = 0;
     int vtN = -1, vtT = -1;    // shape the q/k/vt buffers were last zeroed for
+    int pos_maxlen = COCR_POS_MAXLEN;                  // relative positions the P tables cover: -(max_len - 1) .. max_len - 1
     unsigned char *pre_buf = nullptr;      // line pre-processing: descriptors, tap tables, intermediates
     size_t pre_cap = 0;
     int32_t *d_lens = nullptr, *h_lens = nullptr, *d_lens_cur = nullptr;      // device / pinned-host rings of per-line lengths (upload_lens)
@@ -579,15 +580,15 @@ extern "C" int cocr_finalize(cocr_model *m, int dtype) {
     return COCR_OK;
 }
 
-// P_l = PE Wpos_l^T for all 9999 relative positions (embedding.py:35-56 table, attention.py:62,85 projection), computed on the device in
+// P_l = PE Wpos_l^T for all 2 max_len - 1 relative positions (max_len 5000 as in the reference, longer once a longer line has come) (embedding.py:35-56 table, attention.py:62,85 projection), computed on the device in
 // fp32 from the blob's own wpos matrices and stored head-padded in the compute dtype.  Runs on `s` ahead of a forward's launches (stream
 // order covers a blob import issued on the same stream), never inside a graph capture; the same kernel on the same inputs on every rank,
 // so a rank that received the blob by broadcast holds bit-identical tables.
 template <typename T> static int compute_pos_tables(cocr_model *m, hipStream_t s) {
-    const int D = m->D, R = COCR_POS_ROWS, maxlen = (R + 1) / 2;
+    const int D = m->D, maxlen = m->pos_maxlen, R = 2 * maxlen - 1;
     std::vector<float> pe((size_t)R * D);
     for (int r = 0; r < R; ++r) {
-        const float pos = (float)(maxlen - 1 - r);           // +4999 ... -4999
+        const float pos = (float)(maxlen - 1 - r);           // +(max_len - 1) ... -(max_len - 1)
         for (int i = 0; i < D; i += 2) {
             const float div = expf((float)i * (float)(-(log(10000.0) / D)));
             const float ang = pos * div;
@@ -608,7 +609,7 @@ template <typename T> static int compute_pos_tables(cocr_model *m, hipStream_t s
 }
 static int ensure_ptab(cocr_model *m, hipStream_t s) {
     if (!m->ptab_stale) return COCR_OK;
-    m->ptab_stride = (size_t)COCR_POS_ROWS * m->heads * m->dhp * esize(m->dtype);
+    m->ptab_stride = (size_t)(2 * m->pos_maxlen - 1) * m->heads * m->dhp * esize(m->dtype);
     if (!m->ptab) {
         HIP_TRY(hipMalloc((void **)&m->ptab, m->ptab_stride * m->L));
         HIP_TRY(hipMemsetAsync(m->ptab, 0, m->ptab_stride * m->L, s));          // padded head dims read as zero
@@ -749,7 +750,7 @@ extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, d
 
 template <typename T, int DHP>
 static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
-                                   const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, unsigned long long *stamps = nullptr) {
+                                   const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, int pos_center, unsigned long long *stamps = nullptr) {
     const size_t lds = attention_lds_bytes<T, DHP>();
     auto kern = relpos_attention_kernel<T, DHP>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
@@ -759,7 +760,7 @@ static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k,
     // (80-query tiles -- 5 waves, 512 workgroups = one round of 2 per CU at cfg2 instead of 1280 in two rounds -- measured SLOWER:
     // 19.4 us against 16.3 us per launch)
     hipLaunchKernelGGL(kern, dim3(ceil_div(Tn, 64), N * heads), dim3(256), lds, s, q, k, v, ptab, ub, vb, ctx, Tn, Tp, heads, dh,
-                       scale * 1.44269504088896340736f, stamps);
+                       scale * 1.44269504088896340736f, pos_center, stamps);
     return hipGetLastError();
 }
 
@@ -989,7 +990,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 const LayerW &w = P.layers[l];
                 {
                     ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
                     if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
                 }
@@ -1050,7 +1051,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1)))
             if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
         }
@@ -1150,8 +1151,21 @@ static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N
     if (m->dtype < 0 || !m->blob) return fail(COCR_ESTATE, "model not finalized");
     if (H != m->H) return fail(COCR_EINVAL, "line height %d does not match the model's height %d", H, m->H);
     if (N < 1 || W < 1) return fail(COCR_EINVAL, "empty batch");
-    if (cocr_out_len(W, m->hp.subsampling_factor) > 4900) return fail(COCR_EUNSUPPORTED, "more than 4900 output frames");
     HIP_TRY(hipSetDevice(m->device));
+    {   // the attention core reads the band of whole 64-key tiles unclamped: the tables must cover |relative position| < round_up(T, 64).
+        // A longer line than the tables hold: rebuild them (the reference's RelPositionalEncoding.extend_pe, embedding.py:35-41;
+        // a position's encoding does not depend on the table length, so shorter lines keep their results)
+        const int Tp64 = round_up(cocr_out_len(W, m->hp.subsampling_factor), 64);
+        if (Tp64 > 65536) return fail(COCR_EUNSUPPORTED, "more than 65536 output frames");
+        if (Tp64 + 64 > m->pos_maxlen) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);      // captured launches point at the old tables
+            m->graphs.clear(); m->graph_seen.clear();
+            if (m->ptab) { (void)hipFree(m->ptab); m->ptab = nullptr; }
+            m->pos_maxlen = round_up(Tp64 + 64, 1024);
+            m->ptab_stale = true;
+        }
+    }
     int rc = cocr_reserve(m, N, W);
     if (rc) return rc;
     if (in_lens && out_lens)

@@ -90,6 +90,7 @@ class Oracle:
             if self.bf16 and t.is_floating_point() and self._is_product_weight(k, t):
                 t = self.r(t)
             self.w[k] = t
+        self._maxlen = POS_MAX_LEN
         self._pe = sinusoid_table(hp.encoder_dim).to(dtype)
         self._ptab: Dict[int, torch.Tensor] = {}
 
@@ -201,8 +202,12 @@ class Oracle:
         q = self.r(xn @ self.w[a + 'query_proj.linear.weight'].t() + self.w[a + 'query_proj.linear.bias']).view(B, T, h, dh)
         k = self.r(xn @ self.w[a + 'key_proj.linear.weight'].t() + self.w[a + 'key_proj.linear.bias']).view(B, T, h, dh)
         v = self.r(xn @ self.w[a + 'value_proj.linear.weight'].t() + self.w[a + 'value_proj.linear.bias']).view(B, T, h, dh)
-        P = self.pos_table(l).view(-1, h, dh)                                  # (9999,h,dh)
-        cen = POS_MAX_LEN - 1
+        if T > self._maxlen:                                                   # embedding.py:35-41: the table is rebuilt for a longer input
+            self._maxlen = T
+            self._pe = sinusoid_table(hp.encoder_dim, T).to(self.dtype)
+            self._ptab = {}
+        P = self.pos_table(l).view(-1, h, dh)                                  # (2 max_len - 1, h, dh)
+        cen = self._maxlen - 1
         i = torch.arange(T).view(T, 1)
         j = torch.arange(T).view(1, T)
         rel = cen - (i - j)                                                    # row index of P for (i,j)

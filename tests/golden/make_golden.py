@@ -256,6 +256,22 @@ def tiny2_case(meta):
     meta['tiny2']['encoder_state_keys'] = [(k, list(v.shape), str(v.dtype)) for k, v in enc2.state_dict().items()]
 
 
+def long_case(meta):
+    """tiny_long: one line of 5150 frames -- longer than RelPositionalEncoding(max_len=5000): the reference rebuilds its table
+    (embedding.py:35-41).  Stored: the logits of the first and last 256 frames, the labels of all."""
+    hp = synth.hparams('tiny')
+    image, lens = synth.make_lines(1, hp.height, 20600, seed=1240)
+    state = synth.make_state_dict(hp, seed=1240, decoder_gain=8.0)
+    enc, dec = build_reference(hp, state)
+    logits, olens = reference_forward(enc, dec, image, lens)
+    np.savez_compressed(os.path.join(HERE, 'tiny_long.npz'), out_lens=olens, decoder_bias=state['decoder.bias'],
+                        labels=np.argmax(logits, -1).astype(np.int16), margins=margins(logits).astype(np.float16),
+                        logits_first=logits[:, :256], logits_last=logits[:, -256:])
+    meta['tiny_long'] = {'hparams': hp.as_dict(), 'seed': 1240, 'line_seed': 1240, 'decoder_gain': 8.0, 'N': 1, 'W': 20600,
+                         'widths': [int(x) for x in lens], 'sha256_logits': hashlib.sha256(logits.tobytes()).hexdigest(), 'frames': int(olens[0])}
+    print('tiny_long', meta['tiny_long']['frames'], 'frames')
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -266,10 +282,10 @@ def main():
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
-    if len(sys.argv) > 1 and sys.argv[1] == 'tiny2':      # only the factor-2 fixture, merged into the existing meta.json
+    if len(sys.argv) > 1 and sys.argv[1] in ('tiny2', 'long'):      # only that fixture, merged into the existing meta.json
         with open(os.path.join(HERE, 'meta.json')) as fp:
             meta = json.load(fp)
-        tiny2_case(meta)
+        (tiny2_case if sys.argv[1] == 'tiny2' else long_case)(meta)
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
@@ -283,6 +299,7 @@ def main():
     _, enc8, _ = run_case(meta, 'tiny8', hp8, 1235, 2, 96, widths=[96, 61])
     meta['tiny8']['encoder_state_keys'] = [(k, list(v.shape), str(v.dtype)) for k, v in enc8.state_dict().items()]
     tiny2_case(meta)
+    long_case(meta)
     # cfg1: default_specs.py verbatim, BASELINE configs[0]: 4 lines 96x512 (lens 512,400,300,512)
     hp1 = synth.hparams('cfg1')
     _, enc1, _ = run_case(meta, 'cfg1', hp1, 1235, 4, 512, widths=[512, 400, 300, 512])

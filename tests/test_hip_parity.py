@@ -81,6 +81,23 @@ def test_fp32_logits_within_1e3(case, name):
     assert dev <= FP32_TOL and mism == 0
 
 
+def test_line_longer_than_the_positional_table(case, golden_meta):
+    """5150 output frames: the reference rebuilds its relative-position table beyond max_len = 5000 (embedding.py:35-41); the library
+    rebuilds its P tables the same way (and a short line afterwards still gets its old result).  fp32 logits of the first and last 256
+    frames within 1e-3 of the reference's, every frame label equal outside the margin filter."""
+    hp, state, image, lens, g = case('tiny_long')
+    _, short_before, _ = run_hip(hp, state, image[:, :, :, :400].copy(), np.array([400]), 'fp32')
+    eng, logits, out_lens = run_hip(hp, state, image, lens, 'fp32')
+    T = int(g['out_lens'][0])
+    assert int(out_lens[0]) == T == 5150
+    assert np.abs(logits[:, :256] - g['logits_first']).max() <= FP32_TOL
+    assert np.abs(logits[:, T - 256:T] - g['logits_last']).max() <= FP32_TOL
+    sel = g['margins'] > 1e-2
+    assert (logits.argmax(-1)[sel] == g['labels'][sel]).all()
+    lg2, _ = eng.forward(torch.from_numpy(image[:, 0, :, :400].copy()).cuda(), np.array([400], dtype=np.int32))
+    np.testing.assert_array_equal(lg2.cpu().numpy(), short_before)       # the longer table holds the same encodings
+
+
 def test_fp32_cfg2_full_batch(case):
     """BASELINE configs[1]: 32 lines of 96x1200; logits of lines 0..3 and the labels of all 32 lines."""
     dev, mism, *_ = _check_case(case, 'cfg2', 'fp32')
@@ -190,18 +207,22 @@ def test_cfg2_kernels_on_odd_shapes(n, w):
     assert dev <= 0.25, dev
 
 
-def test_longest_supported_line_and_the_error_beyond_it():
-    """4900 output frames is the documented limit (the positional table has 9999 rows): one frame more is refused with
-    NotImplementedError (COCR_EUNSUPPORTED), not computed wrongly."""
+def test_the_metric_model_on_a_line_at_and_beyond_the_reference_table_length():
+    """The row-chain / 64-key attention path on 4900 and 5121 output frames (the latter beyond the 9999-row table of the reference's
+    max_len = 5000: the library rebuilds its tables, test_line_longer_than_the_positional_table checks the values on the small model)."""
     from conformer_ocr_amd import synth
     hp = synth.hparams('cfg2', num_encoder_layers=1)
     state = synth.make_state_dict(hp, seed=5, decoder_gain=8.0)
     eng = make_engine(hp, state, 'bf16')
     w_ok = 4 * 4900 - 3                         # T = 4900
     assert eng.out_len(w_ok) == 4900 and eng.out_len(w_ok + 4) == 4901
-    x = torch.zeros((1, hp.height, w_ok + 4), dtype=torch.uint8, device='cuda')
-    with pytest.raises(NotImplementedError):
-        eng.forward(x, [w_ok + 4])
+    x = torch.rand((1, hp.height, 4 * 5121 - 3), dtype=torch.float32, device='cuda')
     logits, out_lens = eng.forward(x[:, :, :w_ok].contiguous(), [w_ok])
     torch.cuda.synchronize()
     assert logits.shape == (1, 4900, hp.num_classes) and out_lens.tolist() == [4900] and bool(torch.isfinite(logits).all())
+    first = logits.cpu().numpy().copy()
+    longer, out_lens = eng.forward(x, [x.shape[2]])
+    torch.cuda.synchronize()
+    assert longer.shape == (1, 5121, hp.num_classes) and out_lens.tolist() == [5121] and bool(torch.isfinite(longer).all())
+    again, _ = eng.forward(x[:, :, :w_ok].contiguous(), [w_ok])
+    np.testing.assert_array_equal(again.cpu().numpy(), first)
