@@ -86,7 +86,9 @@ struct cocr_model {
     cocr_hparams hp;
     int device = 0;
     // derived
-    int D, C, L, heads, dh, dhp, ff, ksz, ncls, H, snum;
+    int D, C, L, heads, dh, dhp, ff, ksz, ncls, H, snum;      // D / ff / dh / dhp: the ENGINE's dimensions (zero-padded when `padded`)
+    int rD = 0, rff = 0, rdh = 0;                      // the model's own encoder_dim, feed-forward width, d_head (tensor shapes, LayerNorm width, 1/sqrt(d_head))
+    bool padded = false;                               // bf16, 128 <= encoder_dim < 256: the model runs as a zero-padded 256-wide one (set_engine_dims)
     std::vector<int> feats;   // height after each stride-2 stage: feats[0] = F1, ...
     std::map<std::string, HostTensor> host;
     std::vector<std::string> names;
@@ -125,6 +127,8 @@ struct cocr_model {
     bool amax_ok = false;                   // the forward's launch sequence (plain or captured) ends with the argmax epilogue
     float *ctc_val = nullptr;
     size_t ctc_cap = 0;
+    float *tr_pad = nullptr;            // padded models: engine-layout staging of the output layer's gradient tensors
+    size_t tr_pad_cap = 0;
     int32_t *beam_bp = nullptr;
     size_t beam_cap = 0;
     int lens_cap = 0;
@@ -145,6 +149,7 @@ struct cocr_model {
     std::vector<GraphEntry> graphs, graph_seen;
     bool debug = false;
     unsigned long long *stamps = nullptr;   // COCR_CHAIN_STAMPS=1 (dev builds): host-visible cycle stamps of the frontend / attention / beam kernels, printed at destroy
+    bool no_pad = false;         // COCR_NO_PAD=1: never run a narrow model as a zero-padded 256-wide one
     bool beam_ref = false;       // COCR_BEAM_REF=1: the exhaustive beam kernel (all beam x C candidates per frame) also for <= 256 classes
     bool no_front96 = false;     // COCR_NO_FRONT96=1: frontend conv stages as separate kernels (A/B)
     bool no_conv_mfma = false;   // COCR_NO_CONV_MFMA=1: the all-VALU fp32 frontend conv kernel also in bf16 mode (A/B)
@@ -200,7 +205,9 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     m->D = hp->encoder_dim; m->C = hp->subsampling_conv_channels; m->L = hp->num_encoder_layers;
     m->heads = hp->num_attention_heads; m->dh = dh; m->dhp = round_up(dh, 32);
     m->ff = hp->feed_forward_expansion_factor * hp->encoder_dim; m->ksz = hp->conv_kernel_size;
+    m->rD = m->D; m->rff = m->ff; m->rdh = m->dh;
     m->ncls = hp->num_classes; m->H = hp->height; m->snum = snum;
+    { const char *e = getenv("COCR_NO_PAD"); m->no_pad = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CHAIN"); m->no_chain = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_ROWS"); m->chain_rows = e ? atoi(e) : 0; }
@@ -316,6 +323,7 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->ctc_lab) (void)hipFree(m->ctc_lab);
     if (m->ctc_val) (void)hipFree(m->ctc_val);
     if (m->beam_bp) (void)hipFree(m->beam_bp);
+    if (m->tr_pad) (void)hipFree(m->tr_pad);
     if (m->loss_d) (void)hipFree(m->loss_d);
     if (m->loss_h) (void)hipHostFree(m->loss_h);
     if (m->loss_ws) (void)hipFree(m->loss_ws);
@@ -430,9 +438,33 @@ static int expect_shape(const cocr_model *m, const std::string &name, std::initi
 
 static int ensure_ptab(cocr_model *m, hipStream_t s);
 
+// The row-chain kernels exist for encoder_dim 256 and 512.  A narrower model (the reference's default: encoder_dim 144, 4 heads of 36,
+// feed-forward 576) ran one kernel per product and was SLOWER than the 256-wide model.  In bf16 mode such a model is run as a zero-padded
+// 256-wide one: every tensor is embedded in the 256 / 768-wide layout at pack time (model dimension: identity + zeros; head dimension:
+// head h at columns [64 h, 64 h + d_head); feed-forward: identity + zeros), so every padded activation column is exactly zero at every
+// stage (zero weights and biases, zero LayerNorm gain and shift, silu(0) = 0, 0 * sigmoid(0) = 0) and the real columns see the same
+// sums.  What does not follow from the padding is stated separately: LayerNorm divides by the REAL width (the statistics are raw
+// moments: zeros add nothing), the attention scale is 1 / sqrt(real d_head), the sinusoids use the real encoder_dim.
+static void free_workspace(cocr_model *m);
+static int set_engine_dims(cocr_model *m, int dtype) {
+    const int slot = m->heads > 0 && 256 % m->heads == 0 ? 256 / m->heads : 0;
+    const bool pad = dtype == COCR_BF16 && !m->no_pad && m->rD >= 128 && m->rD < 256 && slot >= m->rdh && slot % 32 == 0 && slot <= 128 && m->rff <= 1024;
+    const int D = pad ? 256 : m->rD, ff = pad ? round_up(m->rff, 256) : m->rff, dh = pad ? slot : m->rdh, dhp = pad ? slot : round_up(m->rdh, 32);
+    if (D != m->D || ff != m->ff || dh != m->dh || dhp != m->dhp) {      // workspace and captured launches belong to the old layout
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear(); m->graph_seen.clear();
+        free_workspace(m);
+        m->capN = m->capW = 0;
+    }
+    m->D = D; m->ff = ff; m->dh = dh; m->dhp = dhp; m->padded = pad;
+    return COCR_OK;
+}
+
 static int alloc_blob(cocr_model *m, int dtype) {
     if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");
     HIP_TRY(hipSetDevice(m->device));
+    { const int rc = set_engine_dims(m, dtype); if (rc) return rc; }
     if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
     if (m->packed) { (void)hipFree(m->packed); m->packed = nullptr; }
     if (m->ptab) { (void)hipFree(m->ptab); m->ptab = nullptr; }
@@ -485,15 +517,41 @@ extern "C" int cocr_blob_import(cocr_model *m, const void *src_device, size_t by
     return COCR_OK;
 }
 
+// dst (vrows x vcols, compute dtype) <- src (.. x src_cols): element (r, c) = src[rmap[r]][cmap[c]], zero where a map says -1
+static void put_mapped(unsigned char *dst, int dtype, const float *src, int src_cols, const std::vector<int> &rmap, const std::vector<int> &cmap) {
+    const size_t vcols = cmap.size();
+    for (size_t r = 0; r < rmap.size(); ++r)
+        for (size_t c = 0; c < vcols; ++c) {
+            const float v = (rmap[r] >= 0 && cmap[c] >= 0) ? src[(size_t)rmap[r] * src_cols + cmap[c]] : 0.0f;
+            if (dtype == COCR_BF16) ((uint16_t *)dst)[r * vcols + c] = f32_to_bf16(v);
+            else ((float *)dst)[r * vcols + c] = v;
+        }
+}
+static void put_vec(unsigned char *dst, const float *src, const std::vector<int> &map) {
+    for (size_t i = 0; i < map.size(); ++i) ((float *)dst)[i] = map[i] >= 0 ? src[map[i]] : 0.0f;
+}
+
 extern "C" int cocr_finalize(cocr_model *m, int dtype) {
     if (!m) return fail(COCR_EINVAL, "null argument");
     if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");
-    const int D = m->D, C = m->C, ff = m->ff, k = m->ksz, h = m->heads, dh = m->dh;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc;
+    if ((rc = set_engine_dims(m, dtype))) return rc;
+    // tensor shapes: the model's own (rD, rff, h x rdh); blob layout: the engine's (D, ff, h x dh) -- the same unless the model is padded
+    const int rD = m->rD, rff = m->rff, rdh = m->rdh, D = m->D, C = m->C, ff = m->ff, k = m->ksz, h = m->heads, dh = m->dh;
+    std::vector<int> Mm(D), Fm(ff), Am(D), Gm((size_t)2 * D), ident_cls(m->ncls);      // engine index -> model index (-1: zero)
+    for (int c = 0; c < D; ++c) Mm[c] = c < rD ? c : -1;                                // model dimension
+    for (int c = 0; c < ff; ++c) Fm[c] = c < rff ? c : -1;                              // feed-forward dimension
+    for (int c = 0; c < D; ++c) Am[c] = (c / dh < h && c % dh < rdh) ? (c / dh) * rdh + c % dh : -1;      // head-major dimension: head hh at [dh hh, dh hh + rdh)
+    for (int n = 0; n < 2 * D; ++n) {   // GLU interleave: packed row 32j + c <- value row 16j + c ; packed row 32j + 16 + c <- gate row D + 16j + c
+        const int tn = n >> 4, c = n & 15, j = tn >> 1, v = 16 * j + c;
+        Gm[n] = v < rD ? ((tn & 1) ? rD + v : v) : -1;
+    }
+    for (int c = 0; c < m->ncls; ++c) ident_cls[c] = c;
     const BlobPlan plan = make_plan(m, dtype);
     std::vector<unsigned char> stage(plan.total, 0);
     unsigned char *st = stage.data();
     const HostTensor *t = nullptr;
-    int rc;
     char buf[256];
 #define GET(NAME, ...)                                          \
     if ((rc = expect_shape(m, NAME, {__VA_ARGS__}, &t))) return rc;
@@ -507,70 +565,62 @@ extern "C" int cocr_finalize(cocr_model *m, int dtype) {
     }
     {   // flatten order: the reference's feature index is c*F + f (convolution.py:235-236); ours is f*C + c
         const int F = m->feats.back();
-        GET("encoder.conv_subsample.out.0.weight", D, (int64_t)C * F);
+        GET("encoder.conv_subsample.out.0.weight", rD, (int64_t)C * F);
         std::vector<int> colmap((size_t)F * C);
         for (int f = 0; f < F; ++f) for (int c = 0; c < C; ++c) colmap[(size_t)f * C + c] = c * F + f;
-        put_matrix(st + plan.wout, dtype, t->data.data(), D, F * C, nullptr, &colmap);
-        GET("encoder.conv_subsample.out.0.bias", D); put_f32(st + plan.bout, t->data.data(), D);
+        put_mapped(st + plan.wout, dtype, t->data.data(), F * C, Mm, colmap);
+        GET("encoder.conv_subsample.out.0.bias", rD); put_vec(st + plan.bout, t->data.data(), Mm);
     }
     for (int l = 0; l < m->L; ++l) {
         const LayerW &w = plan.layers[l];
         auto key = [&](const char *suffix) { snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.%s", l, suffix); return std::string(buf); };
         for (int i = 0; i < 2; ++i) {
             const std::string pre = std::string(i == 0 ? "0" : "3") + ".module.sequential.";
-            GET(key((pre + "0.weight").c_str()), D); put_f32(st + w.ffn[i].ln_g, t->data.data(), D);
-            GET(key((pre + "0.bias").c_str()), D); put_f32(st + w.ffn[i].ln_b, t->data.data(), D);
-            GET(key((pre + "1.linear.weight").c_str()), ff, D); put_matrix(st + w.ffn[i].w1, dtype, t->data.data(), ff, D);
-            GET(key((pre + "1.linear.bias").c_str()), ff); put_f32(st + w.ffn[i].b1, t->data.data(), ff);
-            GET(key((pre + "4.linear.weight").c_str()), D, ff); put_matrix(st + w.ffn[i].w2, dtype, t->data.data(), D, ff);
-            GET(key((pre + "4.linear.bias").c_str()), D); put_f32(st + w.ffn[i].b2, t->data.data(), D);
+            GET(key((pre + "0.weight").c_str()), rD); put_vec(st + w.ffn[i].ln_g, t->data.data(), Mm);
+            GET(key((pre + "0.bias").c_str()), rD); put_vec(st + w.ffn[i].ln_b, t->data.data(), Mm);
+            GET(key((pre + "1.linear.weight").c_str()), rff, rD); put_mapped(st + w.ffn[i].w1, dtype, t->data.data(), rD, Fm, Mm);
+            GET(key((pre + "1.linear.bias").c_str()), rff); put_vec(st + w.ffn[i].b1, t->data.data(), Fm);
+            GET(key((pre + "4.linear.weight").c_str()), rD, rff); put_mapped(st + w.ffn[i].w2, dtype, t->data.data(), rff, Mm, Fm);
+            GET(key((pre + "4.linear.bias").c_str()), rD); put_vec(st + w.ffn[i].b2, t->data.data(), Mm);
         }
-        GET(key("1.module.layer_norm.weight"), D); put_f32(st + w.a_ln_g, t->data.data(), D);
-        GET(key("1.module.layer_norm.bias"), D); put_f32(st + w.a_ln_b, t->data.data(), D);
+        GET(key("1.module.layer_norm.weight"), rD); put_vec(st + w.a_ln_g, t->data.data(), Mm);
+        GET(key("1.module.layer_norm.bias"), rD); put_vec(st + w.a_ln_b, t->data.data(), Mm);
         const char *proj[3] = {"query", "key", "value"};
         for (int j = 0; j < 3; ++j) {
             snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.1.module.attention.%s_proj.linear.weight", l, proj[j]);
-            GET(std::string(buf), D, D); put_matrix(st + w.wqkv + (size_t)j * D * D * esize(dtype), dtype, t->data.data(), D, D);
+            GET(std::string(buf), rD, rD); put_mapped(st + w.wqkv + (size_t)j * D * D * esize(dtype), dtype, t->data.data(), rD, Am, Mm);
             snprintf(buf, sizeof buf, "encoder.layers.%d.sequential.1.module.attention.%s_proj.linear.bias", l, proj[j]);
-            GET(std::string(buf), D); put_f32(st + w.bqkv + (size_t)j * D * 4, t->data.data(), D);
+            GET(std::string(buf), rD); put_vec(st + w.bqkv + (size_t)j * D * 4, t->data.data(), Am);
         }
-        GET(key("1.module.attention.u_bias"), h, dh); put_f32(st + w.ub, t->data.data(), D);
-        GET(key("1.module.attention.v_bias"), h, dh); put_f32(st + w.vb, t->data.data(), D);
-        GET(key("1.module.attention.pos_proj.linear.weight"), D, D); put_f32(st + w.wpos, t->data.data(), (size_t)D * D);
-        GET(key("1.module.attention.out_proj.linear.weight"), D, D); put_matrix(st + w.wo, dtype, t->data.data(), D, D);
-        GET(key("1.module.attention.out_proj.linear.bias"), D); put_f32(st + w.bo, t->data.data(), D);
-        GET(key("2.module.sequential.0.weight"), D); put_f32(st + w.c_ln_g, t->data.data(), D);
-        GET(key("2.module.sequential.0.bias"), D); put_f32(st + w.c_ln_b, t->data.data(), D);
-        {   // GLU interleave: packed row 32j + c <- value row 16j + c ; packed row 32j + 16 + c <- gate row D + 16j + c
-            std::vector<int> rowmap((size_t)2 * D);
-            for (int n = 0; n < 2 * D; ++n) {
-                const int tn = n >> 4, c = n & 15, j = tn >> 1;
-                rowmap[n] = (tn & 1) ? D + 16 * j + c : 16 * j + c;
-            }
-            GET(key("2.module.sequential.2.conv.weight"), 2 * D, D, 1); put_matrix(st + w.wpw1, dtype, t->data.data(), 2 * D, D, &rowmap);
-            GET(key("2.module.sequential.2.conv.bias"), 2 * D);
-            for (int n = 0; n < 2 * D; ++n) ((float *)(st + w.bpw1))[n] = t->data[rowmap[n]];
-        }
+        GET(key("1.module.attention.u_bias"), h, rdh); put_vec(st + w.ub, t->data.data(), Am);
+        GET(key("1.module.attention.v_bias"), h, rdh); put_vec(st + w.vb, t->data.data(), Am);
+        GET(key("1.module.attention.pos_proj.linear.weight"), rD, rD); put_mapped(st + w.wpos, COCR_F32, t->data.data(), rD, Am, Mm);
+        GET(key("1.module.attention.out_proj.linear.weight"), rD, rD); put_mapped(st + w.wo, dtype, t->data.data(), rD, Mm, Am);
+        GET(key("1.module.attention.out_proj.linear.bias"), rD); put_vec(st + w.bo, t->data.data(), Mm);
+        GET(key("2.module.sequential.0.weight"), rD); put_vec(st + w.c_ln_g, t->data.data(), Mm);
+        GET(key("2.module.sequential.0.bias"), rD); put_vec(st + w.c_ln_b, t->data.data(), Mm);
+        GET(key("2.module.sequential.2.conv.weight"), 2 * rD, rD, 1); put_mapped(st + w.wpw1, dtype, t->data.data(), rD, Gm, Mm);
+        GET(key("2.module.sequential.2.conv.bias"), 2 * rD); put_vec(st + w.bpw1, t->data.data(), Gm);
         {   // BatchNorm (eval) folded into the depthwise taps: s = gamma / sqrt(var + eps)
             const HostTensor *wd, *g, *b, *mu, *var;
-            if ((rc = expect_shape(m, key("2.module.sequential.4.conv.weight"), {D, 1, k}, &wd))) return rc;
-            if ((rc = expect_shape(m, key("2.module.sequential.5.weight"), {D}, &g))) return rc;
-            if ((rc = expect_shape(m, key("2.module.sequential.5.bias"), {D}, &b))) return rc;
-            if ((rc = expect_shape(m, key("2.module.sequential.5.running_mean"), {D}, &mu))) return rc;
-            if ((rc = expect_shape(m, key("2.module.sequential.5.running_var"), {D}, &var))) return rc;
-            float *tw = (float *)(st + w.dww), *tb = (float *)(st + w.dwb);
-            for (int c = 0; c < D; ++c) {
+            if ((rc = expect_shape(m, key("2.module.sequential.4.conv.weight"), {rD, 1, k}, &wd))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.weight"), {rD}, &g))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.bias"), {rD}, &b))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.running_mean"), {rD}, &mu))) return rc;
+            if ((rc = expect_shape(m, key("2.module.sequential.5.running_var"), {rD}, &var))) return rc;
+            float *tw = (float *)(st + w.dww), *tb = (float *)(st + w.dwb);      // (padded channels: taps and bias stay zero)
+            for (int c = 0; c < rD; ++c) {
                 const float s = g->data[c] / sqrtf(var->data[c] + 1e-5f);
                 for (int tau = 0; tau < k; ++tau) tw[(size_t)tau * D + c] = wd->data[(size_t)c * k + tau] * s;
                 tb[c] = b->data[c] - mu->data[c] * s;
             }
         }
-        GET(key("2.module.sequential.7.conv.weight"), D, D, 1); put_matrix(st + w.wpw2, dtype, t->data.data(), D, D);
-        GET(key("2.module.sequential.7.conv.bias"), D); put_f32(st + w.bpw2, t->data.data(), D);
-        GET(key("4.weight"), D); put_f32(st + w.f_ln_g, t->data.data(), D);
-        GET(key("4.bias"), D); put_f32(st + w.f_ln_b, t->data.data(), D);
+        GET(key("2.module.sequential.7.conv.weight"), rD, rD, 1); put_mapped(st + w.wpw2, dtype, t->data.data(), rD, Mm, Mm);
+        GET(key("2.module.sequential.7.conv.bias"), rD); put_vec(st + w.bpw2, t->data.data(), Mm);
+        GET(key("4.weight"), rD); put_vec(st + w.f_ln_g, t->data.data(), Mm);
+        GET(key("4.bias"), rD); put_vec(st + w.f_ln_b, t->data.data(), Mm);
     }
-    GET("decoder.weight", m->ncls, D); put_matrix(st + plan.wdec, dtype, t->data.data(), m->ncls, D);
+    GET("decoder.weight", m->ncls, rD); put_mapped(st + plan.wdec, dtype, t->data.data(), rD, ident_cls, Mm);
     GET("decoder.bias", m->ncls); put_f32(st + plan.bdec, t->data.data(), m->ncls);
 #undef GET
     if ((rc = alloc_blob(m, dtype))) return rc;
@@ -585,15 +635,15 @@ extern "C" int cocr_finalize(cocr_model *m, int dtype) {
 // order covers a blob import issued on the same stream), never inside a graph capture; the same kernel on the same inputs on every rank,
 // so a rank that received the blob by broadcast holds bit-identical tables.
 template <typename T> static int compute_pos_tables(cocr_model *m, hipStream_t s) {
-    const int D = m->D, maxlen = m->pos_maxlen, R = 2 * maxlen - 1;
-    std::vector<float> pe((size_t)R * D);
+    const int D = m->D, rD = m->rD, maxlen = m->pos_maxlen, R = 2 * maxlen - 1;      // (a padded model: rD sinusoids, zeros behind them)
+    std::vector<float> pe((size_t)R * D, 0.0f);
     for (int r = 0; r < R; ++r) {
         const float pos = (float)(maxlen - 1 - r);           // +(max_len - 1) ... -(max_len - 1)
-        for (int i = 0; i < D; i += 2) {
-            const float div = expf((float)i * (float)(-(log(10000.0) / D)));
+        for (int i = 0; i < rD; i += 2) {
+            const float div = expf((float)i * (float)(-(log(10000.0) / rD)));
             const float ang = pos * div;
             pe[(size_t)r * D + i] = sinf(ang);
-            if (i + 1 < D) pe[(size_t)r * D + i + 1] = cosf(ang);
+            if (i + 1 < rD) pe[(size_t)r * D + i + 1] = cosf(ang);
         }
     }
     float *d_pe = nullptr;
@@ -667,15 +717,31 @@ extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
 template <typename T> __global__ void to_f32_kernel(const T *in, float *out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = to_f32(in[i]);
 }
+// rows of the engine's (padded) width D -> rows of the model's own width rD: column c of the output is engine column c (model
+// dimension) or, head-major, engine column (c / rdh) * dh + c % rdh
+template <typename T> __global__ void tap_narrow_kernel(const T *in, float *out, size_t rows, int D, int rD, int dh, int rdh, int head_major) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * rD; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / rD;
+        const int c = (int)(i - r * rD);
+        out[i] = to_f32(in[r * D + (head_major ? (c / rdh) * dh + c % rdh : c)]);
+    }
+}
 template <typename T> static int tap(cocr_model *m, hipStream_t s, const std::string &name, const T *src, size_t n) {
     if (!m->debug) return COCR_OK;
+    // a padded model (set_engine_dims): the taps show the model's own columns.  Which taps are rows of D, and in which column order,
+    // follows from their names: q / k / v and the frontend's channel-last tensors have layouts of their own
+    auto ends = [&](const char *suf) { const size_t l = strlen(suf); return name.size() >= l && name.compare(name.size() - l, l, suf) == 0; };
+    const bool own_layout = ends(".q") || ends(".k") || ends(".v") || ends(".z2") || ends(".z3");
+    const bool narrow = m->padded && !own_layout && n % (size_t)m->D == 0;
+    const size_t nout = narrow ? n / m->D * m->rD : n;
     float *dst = nullptr;
-    HIP_TRY(hipMalloc((void **)&dst, n * 4));
-    hipLaunchKernelGGL((to_f32_kernel<T>), dim3(256), dim3(256), 0, s, src, dst, n);
+    HIP_TRY(hipMalloc((void **)&dst, nout * 4));
+    if (narrow) hipLaunchKernelGGL((tap_narrow_kernel<T>), dim3(256), dim3(256), 0, s, src, dst, n / m->D, m->D, m->rD, m->dh, m->rdh, ends(".ctx") ? 1 : 0);
+    else hipLaunchKernelGGL((to_f32_kernel<T>), dim3(256), dim3(256), 0, s, src, dst, n);
     HIP_TRY(hipStreamSynchronize(s));
     auto it = m->taps.find(name);
     if (it != m->taps.end()) (void)hipFree(it->second.first);
-    m->taps[name] = {dst, (int64_t)n};
+    m->taps[name] = {dst, (int64_t)nout};
     return COCR_OK;
 }
 
@@ -849,7 +915,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     T *xn = (T *)m->xn, *hid = (T *)m->hid, *q = (T *)m->q, *k = (T *)m->k, *v = (T *)m->vt, *ctx = (T *)m->ctx, *glu = (T *)m->glu,
       *dwo = (T *)m->dwo;
     const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
-    const float scale = 1.0f / sqrtf((float)dh);
+    const float scale = 1.0f / sqrtf((float)m->rdh);    // (the model's d_head: a padded model's engine d_head is its 64-wide slot)
     const bool rowln = gemm_rowln_supported<T>(D);       // N == D products own whole rows: residual + LayerNorm in their epilogue
     auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
         ProfScope ps(m, s, FAM_LN);
@@ -866,6 +932,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             ProfScope ps(m, s, fam);
             EpiResidualLN<T, 1> e{x, D, F32(bias), alpha, D, resid ? 1 : 0, F32(g1), F32(b1), g2 >= 0 ? F32((size_t)g2) : nullptr,
                                   b2 >= 0 ? F32((size_t)b2) : nullptr, xn};
+            e.Dn = m->rD;
             GEMM_TRY(launch_gemm_rowln<T>(s, A, K, WT(w), K, M, D, K, e));
             return COCR_OK;
         }
@@ -905,7 +972,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             float *partial = reinterpret_cast<float *>(zcur == zb ? za : zb);          // the other frontend buffer is free now
             { ProfScope ps(m, s, FAM_FOUT); GEMM_TRY(launch_gemm_splitk<T>(s, zcur, Kf, WT(P.wout), Kf, M, D, Kf, SPLITS, partial)); }
             ProfScope ps(m, s, FAM_LN);
-            hipLaunchKernelGGL((splitk_reduce_ln_kernel<T>), dim3(ceil_div(M, 16)), dim3(256), 0, s, partial, SPLITS, (size_t)M * D, F32(P.bout), M, D,
+            hipLaunchKernelGGL((splitk_reduce_ln_kernel<T>), dim3(ceil_div(M, 16)), dim3(256), 0, s, partial, SPLITS, (size_t)M * D, F32(P.bout), M, D, m->rD,
                                F32(P.layers[0].ffn[0].ln_g), F32(P.layers[0].ffn[0].ln_b), x, xn);
             LAUNCH_CHECK();
         } else if ((rc = gemm_to_stream(FAM_FOUT, zcur, Kf, P.wout, P.bout, 1.0f, false, P.layers[0].ffn[0].ln_g, P.layers[0].ffn[0].ln_b, -1, -1))) {
@@ -967,7 +1034,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 return COCR_OK;
             };
             auto launch = [&](const ChainArgs &a) { return D == 256 ? launch_rowchain_256(s, a, taps, m->chain_rows) : launch_rowchain_512(s, a, taps, m->chain_rows); };
-            auto base = [&]() { ChainArgs a{}; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; return a; };
+            auto base = [&]() { ChainArgs a{}; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; a.inv_d = 1.0f / (float)m->rD; return a; };
             auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
                 ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha;
                 st.g1 = F32(g1); st.b1 = F32(b1); return st; };
@@ -1424,17 +1491,36 @@ extern "C" int cocr_decoder_backward(cocr_model *m, const float *grad_probits, i
         m->tr_part_cap = need;
     }
     float *part_w = m->tr_part, *part_b = m->tr_part + (size_t)chunks * C * D;
+    // A padded model (set_engine_dims): the kernels work on the engine's D-wide rows (the padded columns of the encoder output and of
+    // the weight are zero, so are their gradients); the caller's tensors have the model's own width rD: strided copies at the boundary.
+    const int rD = m->rD;
+    float *gw_dst = grad_weight, *go_dst = grad_output;
+    if (m->padded) {
+        const size_t need_pad = (size_t)C * D + (grad_output ? (size_t)M * D : 0);
+        if (need_pad > m->tr_pad_cap) {
+            if (m->tr_pad) (void)hipFree(m->tr_pad);
+            m->tr_pad = nullptr; m->tr_pad_cap = 0;
+            HIP_TRY(hipMalloc((void **)&m->tr_pad, need_pad * 4));
+            m->tr_pad_cap = need_pad;
+        }
+        gw_dst = m->tr_pad;
+        if (grad_output) go_dst = m->tr_pad + (size_t)C * D;
+    }
     const dim3 grid(chunks, ceil_div(C, COCR_TR_CT));
     if (m->dtype == COCR_BF16) hipLaunchKernelGGL((decoder_wgrad_kernel<bf16_t>), grid, dim3(256), 0, s, grad_probits, (const bf16_t *)m->xn, M, C, D, part_w, part_b);
     else hipLaunchKernelGGL((decoder_wgrad_kernel<float>), grid, dim3(256), 0, s, grad_probits, (const float *)m->xn, M, C, D, part_w, part_b);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3(ceil_div(C * D, 256)), dim3(256), 0, s, part_w, chunks, (size_t)C * D, grad_weight);
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3(ceil_div(C * D, 256)), dim3(256), 0, s, part_w, chunks, (size_t)C * D, gw_dst);
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, part_b, chunks, (size_t)C, grad_bias);
     LAUNCH_CHECK();
     if (grad_output) {
-        if (m->dtype == COCR_BF16) hipLaunchKernelGGL((decoder_igrad_kernel<bf16_t>), dim3(ceil_div(M, 16)), dim3(256), 0, s, grad_probits, (const bf16_t *)(m->blob + m->plan.wdec), M, C, D, grad_output);
-        else hipLaunchKernelGGL((decoder_igrad_kernel<float>), dim3(ceil_div(M, 16)), dim3(256), 0, s, grad_probits, (const float *)(m->blob + m->plan.wdec), M, C, D, grad_output);
+        if (m->dtype == COCR_BF16) hipLaunchKernelGGL((decoder_igrad_kernel<bf16_t>), dim3(ceil_div(M, 16)), dim3(256), 0, s, grad_probits, (const bf16_t *)(m->blob + m->plan.wdec), M, C, D, go_dst);
+        else hipLaunchKernelGGL((decoder_igrad_kernel<float>), dim3(ceil_div(M, 16)), dim3(256), 0, s, grad_probits, (const float *)(m->blob + m->plan.wdec), M, C, D, go_dst);
         LAUNCH_CHECK();
+    }
+    if (m->padded) {
+        HIP_TRY(hipMemcpy2DAsync(grad_weight, (size_t)rD * 4, gw_dst, (size_t)D * 4, (size_t)rD * 4, C, hipMemcpyDeviceToDevice, s));
+        if (grad_output) HIP_TRY(hipMemcpy2DAsync(grad_output, (size_t)rD * 4, go_dst, (size_t)D * 4, (size_t)rD * 4, M, hipMemcpyDeviceToDevice, s));
     }
     return COCR_OK;
 }
@@ -1447,14 +1533,27 @@ extern "C" int cocr_decoder_adamw(cocr_model *m, const float *grad_weight, const
         return fail(COCR_EINVAL, "invalid AdamW hyper-parameters");            // torch.optim.AdamW's own checks
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
-    const size_t nw = (size_t)m->ncls * m->D, nb = (size_t)m->ncls, n = nw + nb;
+    const size_t nw = (size_t)m->ncls * m->D, nb = (size_t)m->ncls, n = nw + nb, nw_model = (size_t)m->ncls * m->rD;
+    const size_t row_e = (size_t)m->D * 4, row_m = (size_t)m->rD * 4;      // engine / model row bytes of the decoder weight (equal unless padded)
+    if (m->padded) {    // the caller's (ncls, rD) gradient embedded in the engine's zero-padded rows
+        if (nw > m->tr_pad_cap) {
+            if (m->tr_pad) (void)hipFree(m->tr_pad);
+            m->tr_pad = nullptr; m->tr_pad_cap = 0;
+            HIP_TRY(hipMalloc((void **)&m->tr_pad, nw * 4));
+            m->tr_pad_cap = nw;
+        }
+        HIP_TRY(hipMemsetAsync(m->tr_pad, 0, nw * 4, s));
+        HIP_TRY(hipMemcpy2DAsync(m->tr_pad, row_e, grad_weight, row_m, row_m, m->ncls, hipMemcpyDeviceToDevice, s));
+        grad_weight = m->tr_pad;
+    }
     if (!m->tr_state) {
         // fp32 master copy: the state-dict tensors when this rank has them, else (weights received by broadcast) the blob's values
         HIP_TRY(hipMalloc((void **)&m->tr_state, 3 * n * 4));
         HIP_TRY(hipMemsetAsync(m->tr_state + n, 0, 2 * n * 4, s));
         auto w = m->host.find("decoder.weight"), b = m->host.find("decoder.bias");
-        if (w != m->host.end() && w->second.set && w->second.data.size() == nw && b != m->host.end() && b->second.set && b->second.data.size() == nb) {
-            HIP_TRY(hipMemcpyAsync(m->tr_state, w->second.data.data(), nw * 4, hipMemcpyHostToDevice, s));
+        if (w != m->host.end() && w->second.set && w->second.data.size() == nw_model && b != m->host.end() && b->second.set && b->second.data.size() == nb) {
+            HIP_TRY(hipMemsetAsync(m->tr_state, 0, nw * 4, s));
+            HIP_TRY(hipMemcpy2DAsync(m->tr_state, row_e, w->second.data.data(), row_m, row_m, m->ncls, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(m->tr_state + nw, b->second.data.data(), nb * 4, hipMemcpyHostToDevice, s));
             HIP_TRY(hipStreamSynchronize(s));                                   // pageable sources
         } else {
@@ -1484,13 +1583,14 @@ extern "C" int cocr_get_tensor(cocr_model *m, const char *name, float *host_out,
     if (!m || !name || !host_out) return fail(COCR_EINVAL, "null argument");
     const bool is_w = !strcmp(name, "decoder.weight"), is_b = !strcmp(name, "decoder.bias");
     if (!is_w && !is_b) return fail(COCR_EINVAL, "only decoder.weight / decoder.bias are trained by this library (got '%s')", name);
-    const size_t nw = (size_t)m->ncls * m->D, nb = (size_t)m->ncls, n = is_w ? nw : nb;
+    const size_t nw = (size_t)m->ncls * m->D, nb = (size_t)m->ncls, n = is_w ? (size_t)m->ncls * m->rD : nb;      // nw: the engine's (maybe padded) copy
     if ((int64_t)n > max_elems) return fail(COCR_EINVAL, "%s has %zu elements, buffer %lld", name, n, (long long)max_elems);
     auto it = m->host.find(name);
     if (m->tr_state) {
         HIP_TRY(hipSetDevice(m->device));
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        HIP_TRY(hipMemcpy(host_out, m->tr_state + (is_w ? 0 : nw), n * 4, hipMemcpyDeviceToHost));
+        if (is_w) HIP_TRY(hipMemcpy2D(host_out, (size_t)m->rD * 4, m->tr_state, (size_t)m->D * 4, (size_t)m->rD * 4, m->ncls, hipMemcpyDeviceToHost));
+        else HIP_TRY(hipMemcpy(host_out, m->tr_state + nw, n * 4, hipMemcpyDeviceToHost));
         if (it != m->host.end() && it->second.data.size() == n) memcpy(it->second.data.data(), host_out, n * 4);      // a later cocr_finalize keeps the trained values
         return COCR_OK;
     }

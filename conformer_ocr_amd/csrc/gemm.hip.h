@@ -232,6 +232,8 @@ template <typename T, int NV> struct EpiResidualLN {
     float *x; int D; const float *bias; float alpha; int N; int has_resid;
     const float *g1, *b1, *g2, *b2;
     T *xn;
+    int Dn = 0;            // LayerNorm width when D is a zero-padded row width (0: D).  Columns [Dn, D) hold exact zeros: the sums need no mask, the
+                           // centred squares and the divisor do
     __device__ __forceinline__ void transform(int n, const float *v, float *r) const {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = alpha * (v[i] + (n + i < N ? bias[n + i] : 0.f));
@@ -316,8 +318,8 @@ template <typename T, int NV> struct EpiResidualLN {
     }
     // rows m0 .. m0+3 (row r valid if m0 + r < M); staged row r at `staged + r * rs_floats`; xr = rows4_load(m0, M, lane)
     __device__ __forceinline__ void rows4(int m0, int M, const float *staged, int rs_floats, int lane, const Rows4 &xr) const {
-        const int nchunk = D >> 2;
-        const float inv_d = 1.0f / (float)D;
+        const int nchunk = D >> 2, nnorm = (Dn > 0 ? Dn : D) >> 2;
+        const float inv_d = 1.0f / (float)(Dn > 0 ? Dn : D);
         f32x4 xv[4][NV];
         float s[4];
 #pragma unroll
@@ -352,7 +354,7 @@ template <typename T, int NV> struct EpiResidualLN {
                 q[r] = 0.f;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    const bool ok = lane + 64 * v < nchunk;
+                    const bool ok = lane + 64 * v < nnorm;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float d = ok ? xv[r][v][e] - mean[r] : 0.f; q[r] += d * d; }
                 }

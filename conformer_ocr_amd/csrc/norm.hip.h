@@ -119,13 +119,13 @@ static inline void launch_layernorm(hipStream_t s, const float *x, int M, int D,
 // D <= 256 (one float4 chunk per lane).
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float *__restrict__ partial, int splits, size_t zstride, const float *__restrict__ bias,
-                                                               int M, int D, const float *__restrict__ g1, const float *__restrict__ b1,
-                                                               float *__restrict__ x, T *__restrict__ xn) {
+                                                               int M, int D, int Dn, const float *__restrict__ g1, const float *__restrict__ b1,
+                                                               float *__restrict__ x, T *__restrict__ xn) {      // Dn: LayerNorm width (columns [Dn, D) are zero padding)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * 4;
     if (row0 >= M) return;
-    const int nchunk = D >> 2, c = lane, cc = min(c, nchunk - 1);
-    const float inv_d = 1.0f / (float)D;
+    const int nchunk = D >> 2, nnorm = Dn >> 2, c = lane, cc = min(c, nchunk - 1);
+    const float inv_d = 1.0f / (float)Dn;
     const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias + 4 * cc);
     f32x4 v[4];
     float s[4];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float *__re
         const float mean = wave_sum(s[r]) * inv_d;
         float q = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = c < nchunk ? v[r][e] - mean : 0.f; q += d * d; }
+        for (int e = 0; e < 4; ++e) { const float d = c < nnorm ? v[r][e] - mean : 0.f; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
         if (row0 + r < M && c < nchunk) {
             T *p = xn + (size_t)(row0 + r) * D + 4 * c;

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
         }
         if (wait_params && wave < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // this stage's LayerNorm parameters have landed
         lds_fence_barrier();
-        constexpr float inv_d = 1.0f / (float)D;
+        const float inv_d = p.inv_d;                       // (raw moments: zero-padded columns add nothing, the divisor is the real width)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const unsigned char *pr = pbuf + (16 * i + r16) * PROW;

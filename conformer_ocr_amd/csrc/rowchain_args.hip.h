@@ -32,6 +32,7 @@ struct ChainArgs {
     const float *dw_w, *dw_b;      // BatchNorm-folded depthwise taps [k][D] and bias [D]
     bf16_t *tap_dw;        // debug tap (TAPS instantiation): (M, D) copy of the prologue's output, or null
     int dh, dhp, heads, T_, Tp;       // attention layout of the QKV stage
+    float inv_d;           // 1 / (LayerNorm width): 1 / D, or 1 / (the model's own encoder_dim) when D is a zero-padded width (cocr_api: set_engine_dims)
     ChainStage st[4];
 };
 

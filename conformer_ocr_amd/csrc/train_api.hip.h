@@ -134,7 +134,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     for (float p : {p_in, p_ff, p_at, p_cv}) if (!(p >= 0.f && p < 1.f)) return fail(COCR_EINVAL, "dropout probability outside [0, 1)");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
-    const int D = m->D, C = m->C, L = m->L, Hh = m->heads, dh = m->dh, ff = m->ff, K = m->ksz, ncls = m->ncls, snum = m->snum;
+    const int D = m->rD, C = m->C, L = m->L, Hh = m->heads, dh = m->rdh, ff = m->rff, K = m->ksz, ncls = m->ncls, snum = m->snum;      // (the model's own dimensions: the engine's may be padded)
     const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
 
     // ---- shapes of the frontend stages

@@ -233,6 +233,27 @@ def test_fast_path_against_per_product_kernels(text_case, flag, monkeypatch):
     assert all(_greedy(la[n]) == _greedy(lb[n]) == tc.ref_strings[idx[n]] for n in range(len(idx)))
 
 
+def test_narrow_model_as_a_zero_padded_wide_one(case, monkeypatch):
+    """The reference's default model (encoder_dim 144, 4 heads of 36, feed-forward 576) runs in bf16 as a zero-padded 256 / 768-wide model
+    through the row-chain kernels (cocr_api.hip: set_engine_dims).  A/B against the model's own layout on the per-product kernels
+    (COCR_NO_PAD=1): the padding itself adds nothing (zeros), so the difference is what any other accumulation order costs; against
+    the reference's fp32 logits both stay inside the bf16 bound and agree on every frame label outside the margin filter."""
+    hp, state, image, lens, g = case('cfg1')
+    x = torch.from_numpy(image[:, 0]).cuda()
+    a, _ = make_engine(hp, state, 'bf16').forward(x, lens)
+    monkeypatch.setenv('COCR_NO_PAD', '1')
+    b, _ = make_engine(hp, state, 'bf16').forward(x, lens)
+    torch.cuda.synchronize()
+    a, b, ref = a.cpu().numpy(), b.cpu().numpy(), g['logits']
+    d = float(np.abs(a - b).max())
+    da, db = float(np.abs(a - ref).max()), float(np.abs(b - ref).max())
+    _log('ab_COCR_NO_PAD', {'max_abs_logit_diff': d, 'padded_vs_reference': da, 'own_layout_vs_reference': db})
+    assert d > 0.0                       # the flag did select the other layout
+    assert d <= 0.45 and da <= 0.35 and db <= 0.35, (d, da, db)
+    sel = g['margins'] > 0.7
+    assert (a.argmax(-1)[sel] == g['labels'][sel]).all() and (b.argmax(-1)[sel] == g['labels'][sel]).all()
+
+
 def test_bucketed_loop_on_the_wide_model(text_case):
     """BASELINE configs[3] through the drop-in class: `evaluate.recognize` (fixed 200-px buckets, batches of 8, pipelined upload)
     on the D=512 / L=16 model, mixed widths 400..2400; strings equal to the reference's greedy strings of the same padded
