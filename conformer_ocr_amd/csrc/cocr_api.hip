@@ -88,7 +88,7 @@ struct cocr_model {
     // derived
     int D, C, L, heads, dh, dhp, ff, ksz, ncls, H, snum;      // D / ff / dh / dhp: the ENGINE's dimensions (zero-padded when `padded`)
     int rD = 0, rff = 0, rdh = 0;                      // the model's own encoder_dim, feed-forward width, d_head (tensor shapes, LayerNorm width, 1/sqrt(d_head))
-    bool padded = false;                               // bf16, 128 <= encoder_dim < 256: the model runs as a zero-padded 256-wide one (set_engine_dims)
+    bool padded = false;                               // bf16, 128 <= encoder_dim < 512 other than 256: the model runs as a zero-padded 256- / 512-wide one (set_engine_dims)
     std::vector<int> feats;   // height after each stride-2 stage: feats[0] = F1, ...
     std::map<std::string, HostTensor> host;
     std::vector<std::string> names;
@@ -439,17 +439,19 @@ static int expect_shape(const cocr_model *m, const std::string &name, std::initi
 static int ensure_ptab(cocr_model *m, hipStream_t s);
 
 // The row-chain kernels exist for encoder_dim 256 and 512.  A narrower model (the reference's default: encoder_dim 144, 4 heads of 36,
-// feed-forward 576) ran one kernel per product and was SLOWER than the 256-wide model.  In bf16 mode such a model is run as a zero-padded
-// 256-wide one: every tensor is embedded in the 256 / 768-wide layout at pack time (model dimension: identity + zeros; head dimension:
+// feed-forward 576) ran one kernel per product and was SLOWER than the 256-wide model.  In bf16 mode such a model (and one between 256
+// and 512 wide) is run as a zero-padded 256-wide (512-wide) one: every tensor is embedded in the 256 / 768-wide layout at pack time (model dimension: identity + zeros; head dimension:
 // head h at columns [64 h, 64 h + d_head); feed-forward: identity + zeros), so every padded activation column is exactly zero at every
 // stage (zero weights and biases, zero LayerNorm gain and shift, silu(0) = 0, 0 * sigmoid(0) = 0) and the real columns see the same
 // sums.  What does not follow from the padding is stated separately: LayerNorm divides by the REAL width (the statistics are raw
 // moments: zeros add nothing), the attention scale is 1 / sqrt(real d_head), the sinusoids use the real encoder_dim.
 static void free_workspace(cocr_model *m);
 static int set_engine_dims(cocr_model *m, int dtype) {
-    const int slot = m->heads > 0 && 256 % m->heads == 0 ? 256 / m->heads : 0;
-    const bool pad = dtype == COCR_BF16 && !m->no_pad && m->rD >= 128 && m->rD < 256 && slot >= m->rdh && slot % 32 == 0 && slot <= 128 && m->rff <= 1024;
-    const int D = pad ? 256 : m->rD, ff = pad ? round_up(m->rff, 256) : m->rff, dh = pad ? slot : m->rdh, dhp = pad ? slot : round_up(m->rdh, 32);
+    const int wide = m->rD < 256 ? 256 : 512;            // 128 <= encoder_dim < 256 -> 256; 256 < encoder_dim < 512 -> 512
+    const int slot = m->heads > 0 && wide % m->heads == 0 ? wide / m->heads : 0;
+    const bool pad = dtype == COCR_BF16 && !m->no_pad && m->rD >= 128 && m->rD < 512 && m->rD != 256 && slot >= m->rdh && slot % 32 == 0 && slot <= 128 &&
+                     round_up(m->rff, 256) <= (wide == 256 ? 1024 : 2048);
+    const int D = pad ? wide : m->rD, ff = pad ? round_up(m->rff, 256) : m->rff, dh = pad ? slot : m->rdh, dhp = pad ? slot : round_up(m->rdh, 32);
     if (D != m->D || ff != m->ff || dh != m->dh || dhp != m->dhp) {      // workspace and captured launches belong to the old layout
         HIP_TRY(hipDeviceSynchronize());
         for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -920,7 +922,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
         ProfScope ps(m, s, FAM_LN);
         launch_layernorm<T>(s, x, M, D, F32(g1), F32(b1), write_f32 ? x : nullptr, g2 >= 0 ? F32((size_t)g2) : nullptr,
-                            b2 >= 0 ? F32((size_t)b2) : nullptr, xn);
+                            b2 >= 0 ? F32((size_t)b2) : nullptr, xn, m->rD);
         LAUNCH_CHECK();
         return COCR_OK;
     };

@@ -14,7 +14,7 @@
 #define COCR_LN_MAX_D 1024
 
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int M, int D, float eps,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int M, int D, int Dn, float eps,      // Dn: LayerNorm width (columns [Dn, D): zero padding)
                                                         const float *__restrict__ g1, const float *__restrict__ b1,
                                                         float *out_f32,                    // nullable: LN1 result, fp32 (may alias x)
                                                         const float *__restrict__ g2, const float *__restrict__ b2,  // nullable
@@ -23,8 +23,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int M, i
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * 4;
     if (row0 >= M) return;
-    const float inv_d = 1.0f / (float)D;
-    const int nchunk = D >> 2;
+    const float inv_d = 1.0f / (float)Dn;
+    const int nchunk = D >> 2, nnorm = Dn >> 2;
     f32x4 ga[NV], ba[NV], gb[NV], bb[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int M, i
             q[r] = 0.f;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const bool ok = lane + 64 * v < nchunk;
+                const bool ok = lane + 64 * v < nnorm;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = ok ? xv[r][v][e] - mean[r] : 0.f; q[r] += d * d; }
             }
@@ -108,11 +108,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, int M, i
 
 template <typename T>
 static inline void launch_layernorm(hipStream_t s, const float *x, int M, int D, const float *g1, const float *b1,
-                                    float *out_f32, const float *g2, const float *b2, T *out_t) {
+                                    float *out_f32, const float *g2, const float *b2, T *out_t, int Dn = 0) {
     dim3 grid(ceil_div(M, 16));
-    if (D <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
-    else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
-    else hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, dim3(256), 0, s, x, M, D, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
+    if (Dn <= 0) Dn = D;
+    if (D <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, s, x, M, D, Dn, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
+    else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, dim3(256), 0, s, x, M, D, Dn, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
+    else hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, dim3(256), 0, s, x, M, D, Dn, 1e-5f, g1, b1, out_f32, g2, b2, out_t);
 }
 
 // x = sum_z partial[z] + bias (split-K partial sums of the frontend output linear), then LayerNorm -> xn: one wave per 4 rows,

@@ -254,6 +254,30 @@ def test_narrow_model_as_a_zero_padded_wide_one(case, monkeypatch):
     assert (a.argmax(-1)[sel] == g['labels'][sel]).all() and (b.argmax(-1)[sel] == g['labels'][sel]).all()
 
 
+@pytest.mark.parametrize('D,heads,ksz,C', [(160, 4, 31, 32), (192, 8, 31, 64), (208, 4, 15, 32), (144, 2, 31, 32), (240, 8, 7, 256),
+                                          (384, 8, 31, 64), (320, 4, 31, 32), (448, 8, 15, 256)])
+def test_zero_padded_layouts_of_other_narrow_models(D, heads, ksz, C, monkeypatch):
+    """Other widths (to 256 and to 512), head counts (slots of 32, 64 and 128 columns), depthwise kernel sizes (31: fused prologue; others:
+    the separate kernel) and frontends under the zero-padded layout: against the fp32 oracle and against the model's own layout (COCR_NO_PAD=1)."""
+    from tests.hip_util import oracle_taps
+    hp = synth.hparams('cfg1', encoder_dim=D, num_attention_heads=heads, conv_kernel_size=ksz, subsampling_conv_channels=C, num_encoder_layers=2,
+                       num_classes=40)
+    state = synth.make_state_dict(hp, seed=D + heads, decoder_gain=4.0)
+    image, lens = synth.make_lines(3, hp.height, 332, seed=D, widths=[332, 201, 97])
+    ref, ref_lens, _ = oracle_taps(hp, state, image, lens)
+    x = torch.from_numpy(image[:, 0]).cuda()
+    a, ol = make_engine(hp, state, 'bf16').forward(x, lens)
+    monkeypatch.setenv('COCR_NO_PAD', '1')
+    b, _ = make_engine(hp, state, 'bf16').forward(x, lens)
+    torch.cuda.synchronize()
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert ol.tolist() == ref_lens.tolist()
+    da, db, d = float(np.abs(a - ref).max()), float(np.abs(b - ref).max()), float(np.abs(a - b).max())
+    _log(f'pad_{D}_{heads}_{ksz}_{C}', {'padded_vs_oracle': da, 'own_layout_vs_oracle': db, 'padded_vs_own_layout': d})
+    assert d > 0.0 and np.isfinite(a).all()
+    assert da <= 0.15 and db <= 0.15 and d <= 0.15, (da, db, d)
+
+
 def test_bucketed_loop_on_the_wide_model(text_case):
     """BASELINE configs[3] through the drop-in class: `evaluate.recognize` (fixed 200-px buckets, batches of 8, pipelined upload)
     on the D=512 / L=16 model, mixed widths 400..2400; strings equal to the reference's greedy strings of the same padded
