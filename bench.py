@@ -232,7 +232,7 @@ def main():
     torch.cuda.set_device(dev)
 
     # ---- model: the text fixture's weights when the fixture is there (same FLOPs as any other weights; the CER then has a meaning)
-    fix = load_text_fixture({'cfg2': 'cfg2_text', 'cfg4': 'cfg4_text'}.get(args.config, ''))
+    fix = load_text_fixture({'cfg1': 'cfg1_text', 'cfg2': 'cfg2_text', 'cfg4': 'cfg4_text'}.get(args.config, ''))
     hp = fix['hp'] if fix else synth.hparams(args.config)
     S = max(1, args.streams)
     engines = [HipRecognizer(hp, dev, args.dtype) for _ in range(S)]
@@ -434,7 +434,7 @@ def main():
         c_truth.update([got[i] for i in range(n)], fix['texts'])
         cer = {'cer_vs_reference': c_ref.compute(), 'cer_vs_truth': c_truth.compute(), 'lines': n, 'characters': c_truth.total,
                'lines_identical_to_reference': sum(got[i] == fix['ref_strings'][i] for i in range(n)),
-               'fixture': f"tests/golden/{'cfg2_text' if args.config != 'cfg4' else 'cfg4_text'}.npz (reference fp32 greedy strings of the same padded batches)"}
+               'fixture': f"tests/golden/{args.config}_text.npz (reference fp32 greedy strings of the same padded batches)"}
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the forward's stream
     roof, kernels = None, {}

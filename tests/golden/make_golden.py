@@ -240,7 +240,13 @@ def run_text_case(meta, name, hp, seed, widths, batch_size, edge, alphabet=24, h
     return state
 
 
+def text_case_cfg1(meta):
+    # cfg1_text: the reference's default model (default_specs.py: D=144, 16 blocks, 4 heads, C=32) on the metric's batch shape
+    run_text_case(meta, 'cfg1_text', synth.hparams('cfg1'), 2011, [1200] * 32, 32, 0)
+
+
 def text_cases(meta):
+    text_case_cfg1(meta)
     # cfg2_text: the metric's configuration and batch (32 lines of 96x1200), text lines + fitted decoder
     run_text_case(meta, 'cfg2_text', synth.hparams('cfg2'), 2001, [1200] * 32, 32, 0)
     # cfg4_text: BASELINE configs[3] -- wide conformer, widths U{400..2400} step 8, bucket edge 200, batches of <= 8
@@ -282,10 +288,10 @@ def main():
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
-    if len(sys.argv) > 1 and sys.argv[1] in ('tiny2', 'long'):      # only that fixture, merged into the existing meta.json
+    if len(sys.argv) > 1 and sys.argv[1] in ('tiny2', 'long', 'text1'):      # only that fixture, merged into the existing meta.json
         with open(os.path.join(HERE, 'meta.json')) as fp:
             meta = json.load(fp)
-        (tiny2_case if sys.argv[1] == 'tiny2' else long_case)(meta)
+        {'tiny2': tiny2_case, 'long': long_case, 'text1': text_case_cfg1}[sys.argv[1]](meta)
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return

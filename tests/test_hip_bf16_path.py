@@ -161,11 +161,11 @@ def _run_text_fixture(tc, dtype, env=None):
     return labels, heads
 
 
-@pytest.mark.parametrize('name', ['cfg2_text', 'cfg4_text'])
+@pytest.mark.parametrize('name', ['cfg1_text', 'cfg2_text', 'cfg4_text'])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_text_fixture_labels_and_strings(text_case, name, dtype):
     """cfg2_text = BASELINE configs[1]'s model and batch (32 x 96x1200); cfg4_text = configs[3] (D=512, L=16, widths 400..2400 in
-    200-px buckets).  fp32: logits within 1e-3, every frame label equal.  bf16: labels equal on every frame with margin > 1
+    200-px buckets); cfg1_text = the reference's default model (D=144: in bf16 the zero-padded 256-wide layout) on the metric's batch.  fp32: logits within 1e-3, every frame label equal.  bf16: labels equal on every frame with margin > 1
     (>= 95 % of frames, a constant filter), greedy strings identical to the reference's on EVERY line, = the ground truth."""
     tc = text_case(name)
     labels, heads = _run_text_fixture(tc, dtype)
