@@ -215,8 +215,8 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     };
     auto colsum = [&](const float *a, const float *b, int Mr, int Nc, float *out, int accumulate) {
         const int chunks = ceil_div(Mr, COCR_CS_ROWS);
-        hipLaunchKernelGGL(k_colsum_partial, dim3(ceil_div(Nc, 256), chunks), dim3(256), 0, s, a, b, WS(oPart), Mr, Nc);
-        hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 256)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
+        hipLaunchKernelGGL(k_colsum_partial, dim3(ceil_div(Nc, 64), chunks), dim3(256), 0, s, a, b, WS(oPart), Mr, Nc);
+        hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
     };
     // Y (rows, Nc) = X (rows, Kr) W(Nc, Kr)^T + b
     auto lin_fwd = [&](const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *Y) -> int {
@@ -232,7 +232,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             if ((r = gemm(WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, Gp(w), Kr, nullptr))) return r;
         } else {
             GEMM_TRY(launch_gemm_splitk<float>(s, WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, splits, WS(oSplit)));
-            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 256)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
+            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 64)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
         }
         if (!b.empty()) colsum(dY, nullptr, rows, Nc, Gp(b), 0);
         if (dX) {
@@ -398,7 +398,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             hipLaunchKernelGGL(k_bn_bwd, grid1(MD), dim3(256), 0, s, WS(oDc), WS(a.xhat), Pp(key(l, "2.module.sequential.5.weight")), WS(a.bnr), WS(oVec),
                                WS(oVec) + D, WS(oDe), M, D);                                                  // d dwo
             hipLaunchKernelGGL(k_dw1d_bwd_w, dim3(ceil_div(D, 64), K, N), dim3(64), 0, s, WS(oDe), WS(a.g), WS(oLinePart), N, T, D, K);
-            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(D * K, 256)), dim3(256), 0, s, WS(oLinePart), Gp(key(l, "2.module.sequential.4.conv.weight")), N, D * K, 0);
+            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(D * K, 64)), dim3(256), 0, s, WS(oLinePart), Gp(key(l, "2.module.sequential.4.conv.weight")), N, D * K, 0);
             hipLaunchKernelGGL(k_dw1d_bwd_in, grid1(MD), dim3(256), 0, s, WS(oDe), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(oDc), N, T, D, K);   // d g
             hipLaunchKernelGGL(k_glu_bwd, grid1(MD), dim3(256), 0, s, WS(a.ga), WS(oDc), WS(oDwide), M, D);                                              // d a (M, 2D)
             if ((rc = lin_bwd(WS(oDwide), WS(a.xn3), key(l, "2.module.sequential.2.conv.weight"), key(l, "2.module.sequential.2.conv.bias"), M, 2 * D, D, WS(oDc)))) return rc;
@@ -418,7 +418,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
                                arows, T, Hh, dh, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));            // d k -> oDe, d v -> oDa
             (void)hipMemsetAsync(WS(oDP), 0, (size_t)Rp * D * 4, s);
             hipLaunchKernelGGL(k_attn_bwd_pos, dim3(ceil_div(R * Hh, 4), N), dim3(256), 0, s, WS(a.q), vbp, WS(oDsb), WS(oLinePart), N, T, Hh, dh);
-            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(R * D, 256)), dim3(256), 0, s, WS(oLinePart), WS(oDP), N, R * D, 0);
+            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(R * D, 64)), dim3(256), 0, s, WS(oLinePart), WS(oDP), N, R * D, 0);
             colsum(du_part, nullptr, M, D, Gp(key(l, "1.module.attention.u_bias")), 0);
             colsum(dvb_part, nullptr, M, D, Gp(key(l, "1.module.attention.v_bias")), 0);
             hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, du_part, dvb_part, 1.0f, MD);                 // d q

@@ -52,23 +52,33 @@ __global__ static void k_pad_cols(const float *__restrict__ in, float *__restric
         out[i] = c < C ? in[(i / ldo) * C + c] : 0.f;
     }
 }
-// column sums of a (M, N) matrix, optionally of the elementwise product a .* b: part[chunk][n] over 64-row chunks, then out[n] (+)= sum of chunks
-#define COCR_CS_ROWS 64
-__global__ static void k_colsum_partial(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
-    if (n >= N) return;
+// column sums of a (M, N) matrix, optionally of the elementwise product a .* b: part[chunk][n] over COCR_CS_ROWS-row chunks, then
+// out[n] (+)= sum of chunks.  Fixed summation order (bit-reproducible steps): a workgroup = 64 columns x 4 row (chunk) groups, group g
+// takes every fourth row (chunk) in order, the four partial sums are added in order through LDS.  (One thread per column walking all
+// chunks serially -- the first form -- left a (9600, 256) bias gradient to ONE workgroup for 28 us, 474 times per training step.)
+#define COCR_CS_ROWS 256
+__global__ __launch_bounds__(256) static void k_colsum_partial(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 64 + cl, chunk = blockIdx.y;
     const int r0 = chunk * COCR_CS_ROWS, r1 = min(M, r0 + COCR_CS_ROWS);
     float s = 0.f;
-    if (b) for (int r = r0; r < r1; ++r) s = fmaf(a[(size_t)r * N + n], b[(size_t)r * N + n], s);
-    else for (int r = r0; r < r1; ++r) s += a[(size_t)r * N + n];
-    part[(size_t)chunk * N + n] = s;
+    if (n < N) {
+        if (b) for (int r = r0 + rg; r < r1; r += 4) s = fmaf(a[(size_t)r * N + n], b[(size_t)r * N + n], s);
+        else for (int r = r0 + rg; r < r1; r += 4) s += a[(size_t)r * N + n];
+    }
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) part[(size_t)chunk * N + n] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
 }
-__global__ static void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int chunks, int N, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = accumulate ? out[n] : 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * N + n];
-    out[n] = s;
+// out[n] (+)= sum over `chunks` of part[k][n]: the same 64 x 4 arrangement over the chunks
+__global__ __launch_bounds__(256) static void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int chunks, int N, int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6, n = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (n < N) for (int k = kg; k < chunks; k += 4) s += part[(size_t)k * N + n];
+    red[kg][cl] = s;
+    __syncthreads();
+    if (kg == 0 && n < N) out[n] = (accumulate ? out[n] : 0.f) + (((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]);
 }
 
 // ---- LayerNorm (eps 1e-5): one wave per row -----------------------------------------------------------------------------------------------
@@ -164,7 +174,20 @@ __global__ static void k_attn_fwd(const float *__restrict__ q, const float *__re
     for (int j = lane; j < T; j += 64) {
         const float *kr = k + ((size_t)b * T + j) * D + h * dh, *pr = P + (size_t)(T - 1 - (i - j)) * D + h * dh;
         float s = 0.f;
-        for (int d = 0; d < dh; ++d) s = fmaf(qu[d], kr[d], fmaf(qv[d], pr[d], s));
+        if ((dh & 3) == 0 && (D & 3) == 0) {           // 16-byte loads of the two rows (a lane walks its own key's row: every load instruction touches 64 lines)
+            const float4 *k4 = reinterpret_cast<const float4 *>(kr), *p4 = reinterpret_cast<const float4 *>(pr);
+#pragma unroll 4
+            for (int d4 = 0; d4 < (dh >> 2); ++d4) {
+                const float4 kk = k4[d4], pp = p4[d4];
+                const int d = 4 * d4;
+                s = fmaf(qu[d], kk.x, fmaf(qv[d], pp.x, s));
+                s = fmaf(qu[d + 1], kk.y, fmaf(qv[d + 1], pp.y, s));
+                s = fmaf(qu[d + 2], kk.z, fmaf(qv[d + 2], pp.z, s));
+                s = fmaf(qu[d + 3], kk.w, fmaf(qv[d + 3], pp.w, s));
+            }
+        } else {
+            for (int d = 0; d < dh; ++d) s = fmaf(qu[d], kr[d], fmaf(qv[d], pr[d], s));
+        }
         s *= scale;
         ar[j] = s;
         mx = fmaxf(mx, s);
@@ -179,6 +202,7 @@ __global__ static void k_attn_fwd(const float *__restrict__ q, const float *__re
     const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     for (int d = lane; d < dh; d += 64) {
         float acc = 0.f;
+#pragma unroll 8
         for (int j = 0; j < T; ++j) {
             float a = ar[j];
             if (p > 0.f) a = drop_keep(seed, site, (unsigned long long)row * T + j, p) ? a * sc : 0.f;
@@ -206,7 +230,17 @@ __global__ static void k_attn_bwd_rows(const float *__restrict__ dctx, const flo
     for (int j = lane; j < T; j += 64) {
         const float *vr = v + ((size_t)b * T + j) * D + h * dh;
         float da = 0.f;
-        for (int d = 0; d < dh; ++d) da = fmaf(dc[d], vr[d], da);
+        if ((dh & 3) == 0 && (D & 3) == 0) {
+            const float4 *v4 = reinterpret_cast<const float4 *>(vr);
+#pragma unroll 4
+            for (int d4 = 0; d4 < (dh >> 2); ++d4) {
+                const float4 vv = v4[d4];
+                const int d = 4 * d4;
+                da = fmaf(dc[d], vv.x, da); da = fmaf(dc[d + 1], vv.y, da); da = fmaf(dc[d + 2], vv.z, da); da = fmaf(dc[d + 3], vv.w, da);
+            }
+        } else {
+            for (int d = 0; d < dh; ++d) da = fmaf(dc[d], vr[d], da);
+        }
         if (p > 0.f) da = drop_keep(seed, site, (unsigned long long)row * T + j, p) ? da * sc : 0.f;      // d loss / d (undropped attention weight)
         dr[j] = da;
         delta = fmaf(ar[j], da, delta);
@@ -217,6 +251,7 @@ __global__ static void k_attn_bwd_rows(const float *__restrict__ dctx, const flo
     __threadfence_block();
     for (int d = lane; d < dh; d += 64) {
         float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
         for (int j = 0; j < T; ++j) {
             const float ds = dr[j];
             a1 = fmaf(ds, k[((size_t)b * T + j) * D + h * dh + d], a1);
@@ -238,6 +273,7 @@ __global__ static void k_attn_bwd_cols(const float *__restrict__ dctx, const flo
     for (int d = lane; d < dh; d += 64) {
         float a1 = 0.f, a2 = 0.f;
         const float ud = u[h * dh + d];
+#pragma unroll 8
         for (int i = 0; i < T; ++i) {
             const size_t e = ((size_t)bh * T + i) * T + j;
             a1 = fmaf(dsb[e], q[((size_t)b * T + i) * D + h * dh + d] + ud, a1);
@@ -261,6 +297,7 @@ __global__ static void k_attn_bwd_pos(const float *__restrict__ q, const float *
     for (int d = lane; d < dh; d += 64) {
         float acc = 0.f;
         const float vd = vb[h * dh + d];
+#pragma unroll 8
         for (int i = i0; i < i1; ++i)
             acc = fmaf(dsb[(((size_t)b * H + h) * T + i) * T + (i - off)], q[((size_t)b * T + i) * D + h * dh + d] + vd, acc);
         part[((size_t)b * (2 * T - 1) + r) * D + h * dh + d] = acc;
