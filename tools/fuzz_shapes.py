@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Random batch shapes through the measured configuration's kernels (cfg2, one encoder block, bf16) against the fp32 CPU oracle:
+"""Random batch shapes through the measured configuration's kernels (cfg2 or cfg1, one encoder block, bf16) against the fp32 CPU oracle:
 a one-off robustness sweep beyond tests/test_hip_parity.py::test_cfg2_kernels_on_odd_shapes.
 
-    python tools/fuzz_shapes.py [--cases 40] [--seed 0]
+    python tools/fuzz_shapes.py [--cases 40] [--seed 0] [--config cfg2|cfg1]
 """
 import argparse
 import os
@@ -19,11 +19,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=40)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--config', default='cfg2', help="cfg2 (row-chain kernels) or cfg1 (the reference's default model: the zero-padded layout on the same kernels)")
     args = ap.parse_args()
     g = np.random.default_rng(args.seed)
-    hp = synth.hparams('cfg2', num_encoder_layers=1)
+    hp = synth.hparams(args.config, num_encoder_layers=1)
     state = synth.make_state_dict(hp, seed=99, decoder_gain=8.0)
-    worst = 0.0
+    worst, band = 0.0, (0.25 if args.config == 'cfg2' else 0.35)      # (cfg1, one block, decoder gain 8: both of its layouts sit at 0.2 - 0.32)
     for k in range(args.cases):
         n = int(g.integers(1, 7)) if k % 5 else int(g.integers(30, 70))
         w = int(g.integers(9, 1600)) if k % 5 else int(g.integers(9, 400))
@@ -35,10 +36,10 @@ def main():
         assert out_lens.tolist() == ref_lens.tolist(), (n, w, out_lens, ref_lens)
         dev = float(np.abs(logits - ref).max())
         worst = max(worst, dev)
-        flag = '' if dev <= 0.25 and np.isfinite(logits).all() else '   <-- OUT OF BAND'
+        flag = '' if dev <= band and np.isfinite(logits).all() else '   <-- OUT OF BAND'
         print(f'case {k:3d}: n={n:3d} w={w:5d} T={logits.shape[1]:4d} max|dlogit|={dev:.4f}{flag}', flush=True)
     print('worst', worst)
-    return 0 if worst <= 0.25 else 1
+    return 0 if worst <= band else 1
 
 
 if __name__ == '__main__':
