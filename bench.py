@@ -476,6 +476,26 @@ def main():
                 'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command, 2*FETCH+WRITE bytes per launch '
                                   '(newest profiles/*_pmc_traffic.csv; `traffic_profile.stale` compares that round\'s kernel duration with this run\'s)'}
 
+        # the same kernel in its 48-row form (what one batch in flight runs: twice the workgroups, every weight byte streamed twice):
+        # a shorter launch on more CUs at more CU-time; `value` runs the 96-row form
+        if dom.startswith('chain') and not args.no_extra_legs:
+            eng.set_chain_rows(48)
+            torch.cuda.synchronize(dev)
+            for _ in range(3):
+                eng.forward(batches[pb]['x'], batches[pb]['lens'])
+            eng.profile(True)
+            for _ in range(args.profile_steps):
+                lg, ol = eng.forward(batches[pb]['x'], batches[pb]['lens'])
+                eng.ctc_greedy(lg, ol)
+            p48 = eng.profile_read()
+            eng.profile(False)
+            eng.set_chain_rows(0)
+            if dom in p48:
+                ms48 = max(p48[dom][0] - p48.get('event_pair_overhead', (0.0, 0))[0], 1e-6)
+                ach = table[dom][1] / (ms48 * 1e-3) / 1e12
+                roof['rows48'] = {'avg_ms': round(ms48, 5), 'achieved': round(ach, 3), 'frac': round(ach / d['peak'], 5),
+                                  'cus_occupied': min(256, 2 * cus_occupied(dom, hp, rows))}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(hp, state, max_w if args.config != 'cfg4' else 1400, sample_lines=min(32, args.batch) if args.config != 'cfg4' else 8)
