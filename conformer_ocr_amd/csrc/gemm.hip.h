@@ -466,6 +466,11 @@ template <typename T> struct GemmArgs {
     int M, N, K;           // K of ONE split
     int k_zstride;         // split-K: grid.y = number of splits; split z reads k in [z * k_zstride, z * k_zstride + K) and
                            // writes through epi.with_z(z) (0 when unused)
+    // batched products (gemm_ring_kernel with EpiStoreF32; grid.y = batches): batch z = (zb, zh) = (z / z_div, z % z_div) reads A and W
+    // at element offsets zb * ?_zb + zh * ?_zh and writes at out + zb * o_zb + zh * o_zh -- the (line, head) sub-matrices of (M, D)
+    // activations and per-(line, head) square matrices alike.  z_div = 0: not batched.
+    int z_div = 0;
+    long long a_zb = 0, a_zh = 0, w_zb = 0, w_zh = 0, o_zb = 0, o_zh = 0;
 };
 
 __device__ __forceinline__ bf16x8 lds_frag_swz(const unsigned char *row, int kc, int g, int swz, bf16_t) {
@@ -498,6 +503,13 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) 
     const int m0 = (ltile / gx) * BM, n0 = (ltile % gx) * BN;
     const int nk = K / BK;
     if (p.k_zstride) { p.A += (size_t)blockIdx.y * p.k_zstride; p.W += (size_t)blockIdx.y * p.k_zstride; }
+    long long out_off = 0;
+    if (p.z_div) {
+        const int z = blockIdx.y, zb = z / p.z_div, zh = z - zb * p.z_div;
+        p.A += zb * p.a_zb + zh * p.a_zh;
+        p.W += zb * p.w_zb + zh * p.w_zh;
+        out_off = zb * p.o_zb + zh * p.o_zh;
+    }
 
     // Per-lane byte offsets of this thread's DMA pieces are loop-invariant (row clamp + swizzled chunk); a k-tile only moves the
     // UNIFORM base by 128 bytes, so an issue costs no vector arithmetic (it was ~60 VALU instructions per k-tile beside 32 MFMAs).
@@ -561,7 +573,8 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) 
     }
     __syncthreads();                                     // every wave is done reading the ring: reuse it for the staged tile
     if constexpr (std::is_same<Epi, EpiStoreF32>::value) {
-        const EpiStoreF32 ez = epi.with_z(p.k_zstride ? blockIdx.y : 0);
+        EpiStoreF32 ez = epi.with_z(p.k_zstride ? blockIdx.y : 0);
+        ez.out += out_off;
         gemm_epilogue<BM, BN, MI, NI, Epi>(acc, smem, m0, n0, M, N, ez);
     } else {
         gemm_epilogue<BM, BN, MI, NI, Epi>(acc, smem, m0, n0, M, N, epi);
@@ -808,6 +821,19 @@ static inline hipError_t launch_gemm_rowln(hipStream_t s, const T *A, int lda, c
 #define COCR_FO_BN 128
 #define COCR_FO_NST 2
 #endif
+// Batched exact-fp32 products (GemmArgs::z_div): out_z (M x N, row stride ldo) = A_z (M x K) W_z (N x K)^T, K % 32 == 0, 64 x 64 tiles.
+static inline hipError_t launch_gemm_batched_f32(hipStream_t s, GemmArgs<float> a, float *out, int ldo, int batches) {
+    constexpr int BM = 64, BN = 64, NST = 3;
+    if (a.K % 32 || a.z_div < 1 || batches < 1) return hipErrorInvalidValue;
+    EpiStoreF32 e{out, ldo, nullptr, a.N};
+    const size_t lds = std::max((size_t)NST * (BM + BN) * 128, epi_lds_bytes<EpiStoreF32, BM, BN>());
+    auto kern = gemm_ring_kernel<float, BM, BN, NST, EpiStoreF32>;
+    hipError_t err = raise_lds_limit((const void *)kern, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, BN) * ceil_div(a.M, BM), batches), dim3(256), lds, s, a, e);
+    return hipGetLastError();
+}
+
 template <typename T>
 static inline hipError_t launch_gemm_splitk(hipStream_t s, const T *A, int lda, const T *W, int ldw, int M, int N, int K, int splits, float *partial) {
     constexpr int BK = 128 / (int)sizeof(T);

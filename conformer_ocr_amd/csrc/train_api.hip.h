@@ -142,6 +142,9 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     { int tt = W, f = H; for (int i = 0; i < snum; ++i) { tt = out_len1(tt); f = out_len1(f); Ts[i] = tt; Fs[i] = f; } }
     const int T = Ts.back(), F = Fs.back(), M = N * T, Mp = round_up(M, 1024), R = 2 * T - 1, Rp = round_up(R, 1024);
     const int nclp = round_up(ncls, 4);
+    // attention as batched exact-fp32 GEMMs (train_enc.hip.h) when d_head is a whole number of 32-wide k-chunks; else one wave per row
+    const int Tk = round_up(T, 32), Rk = round_up(R, 32), Z = N * Hh;
+    const bool attn_gemm = dh % 32 == 0 && !getenv("COCR_TRAIN_ATTN_NAIVE");
     std::vector<int32_t> out_lens(N);
     for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
 
@@ -163,7 +166,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         Lay &a = lay[l];
         a.x_in = rsv(MD); a.xn1 = rsv(MD); a.mu1 = rsv(M); a.rs1 = rsv(M); a.h1 = rsv((size_t)M * ff); a.a1 = rsv((size_t)M * ff); a.x1 = rsv(MD);
         a.xn2 = rsv(MD); a.mu2 = rsv(M); a.rs2 = rsv(M); a.q = rsv(MD); a.k = rsv(MD); a.v = rsv(MD); a.P = rsv((size_t)R * D);
-        a.attn = rsv((size_t)N * Hh * T * T); a.ctx = rsv(MD); a.x2 = rsv(MD);
+        a.attn = rsv((size_t)N * Hh * T * (attn_gemm ? Tk : T)); a.ctx = rsv(MD); a.x2 = rsv(MD);
         a.xn3 = rsv(MD); a.mu3 = rsv(M); a.rs3 = rsv(M); a.ga = rsv(2 * MD); a.g = rsv(MD); a.dwo = rsv(MD); a.bnm = rsv(D); a.bnr = rsv(D); a.xhat = rsv(MD);
         a.bny = rsv(MD); a.sact = rsv(MD); a.x3 = rsv(MD);
         a.xn4 = rsv(MD); a.mu4 = rsv(M); a.rs4 = rsv(M); a.h4 = rsv((size_t)M * ff); a.a4 = rsv((size_t)M * ff); a.x4 = rsv(MD); a.mu5 = rsv(M); a.rs5 = rsv(M);
@@ -178,7 +181,12 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     const size_t tr_floats = std::max((size_t)wide * Mp, big_rows_p * (size_t)C);
     const size_t oTA = rsv(tr_floats), oTB = rsv(tr_floats), oTW = rsv((size_t)std::max(std::max((size_t)ff * D, (size_t)C * F * D), (size_t)std::max(C * C, D * nclp)) + 1024);
     const size_t oDa = rsv(MD), oDb = rsv(MD), oDc = rsv(MD), oDd = rsv(MD), oDe = rsv(MD), oDwide = rsv((size_t)M * std::max(ff, 2 * D)), oDwide2 = rsv((size_t)M * std::max(ff, 2 * D));
-    const size_t oDsb = rsv((size_t)N * Hh * T * T), oDP = rsv((size_t)Rp * D);
+    const size_t oDsb = rsv((size_t)N * Hh * T * (attn_gemm ? Tk : T)), oDP = rsv((size_t)Rp * D);
+    size_t oQu = 0, oQv = 0, oRm = 0, oAd = 0, oHT = 0, oTT = 0, oDRT = 0, oPmT = 0;
+    if (attn_gemm) {
+        oQu = rsv(MD); oQv = rsv(MD); oRm = rsv((size_t)Z * T * Rk); oAd = rsv((size_t)Z * T * Tk); oHT = rsv((size_t)Z * dh * Tk);
+        oTT = rsv((size_t)Z * T * Tk); oDRT = rsv((size_t)Z * R * Tk); oPmT = rsv((size_t)Hh * dh * Rk);
+    }
     const size_t oZg = rsv((size_t)M * C * F), oZa = rsv(big_rows * C), oZb = rsv(big_rows * C), oZ1g = rsv((size_t)N * Ts[0] * Fs[0] * C);
     const size_t part_floats = std::max((size_t)ceil_div((int)std::min<size_t>(big_rows, 1u << 30), COCR_CS_ROWS) * (size_t)std::max(wide, C * 10),
                                         (size_t)ceil_div((int)std::min<size_t>((size_t)N * Ts[0] * Fs[0], 1u << 30), COCR_CV_POS) * 10 * (size_t)C);
@@ -212,6 +220,25 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     auto transpose = [&](const float *in, float *out, int Rr, int Cc, int ldo) {      // out (Cc, ldo) zero-padded beyond Rr
         (void)hipMemsetAsync(out, 0, (size_t)Cc * ldo * 4, s);
         hipLaunchKernelGGL(k_transpose, dim3(ceil_div(Cc, 32), ceil_div(Rr, 32)), dim3(256), 0, s, in, out, Rr, Cc, ldo);
+    };
+    // out_z (Mr x Nc, stride ldo) = A_z (Mr x Kr) W_z (Nc x Kr)^T over the Z = N * heads (line, head) batches: offsets per (line, head)
+    auto bgemm = [&](const float *A, int lda, long long azb, long long azh, const float *Wm, int ldw, long long wzb, long long wzh, int Mr, int Nc, int Kr,
+                     float *out, int ldo, long long ozb, long long ozh) -> int {
+        GemmArgs<float> a{A, lda, Wm, ldw, Mr, Nc, Kr, 0};
+        a.z_div = Hh; a.a_zb = azb; a.a_zh = azh; a.w_zb = wzb; a.w_zh = wzh; a.o_zb = ozb; a.o_zh = ozh;
+        GEMM_TRY(launch_gemm_batched_f32(s, a, out, ldo, Z));
+        return COCR_OK;
+    };
+    const long long sTD = (long long)T * D, sTT = (long long)T * Tk, sTR = (long long)T * Rk, sHT = (long long)dh * Tk;
+    // head h of an (M, D) activation as (T x dh) matrices -> [z][dh][Tk] (transposed, zero-padded)
+    auto head_T = [&](const float *in, float *out) {
+        hipLaunchKernelGGL(k_btranspose, dim3(ceil_div(Tk, 32), ceil_div(dh, 32), Z), dim3(256), 0, s, in, out, T, dh, (long long)D, (long long)Tk, Tk, Hh, sTD, (long long)dh, sHT,
+                           0, 0.f, 0ull, 0u);
+    };
+    // [z][T][Tk] -> its transpose [z][T][Tk]; drop: the attention weights' dropout applied to the input
+    auto square_T = [&](const float *in, float *out, bool drop, float p, unsigned site) {
+        hipLaunchKernelGGL(k_btranspose, dim3(ceil_div(Tk, 32), ceil_div(T, 32), Z), dim3(256), 0, s, in, out, T, T, (long long)Tk, (long long)Tk, Tk, 1, sTT, 0ll, sTT,
+                           drop ? T : 0, p, (unsigned long long)seed, site);
     };
     auto colsum = [&](const float *a, const float *b, int Mr, int Nc, float *out, int accumulate) {
         const int chunks = ceil_div(Mr, COCR_CS_ROWS);
@@ -322,9 +349,22 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         if ((rc = lin_fwd(WS(a.xn2), key(l, "1.module.attention.key_proj.linear.weight"), key(l, "1.module.attention.key_proj.linear.bias"), M, D, D, WS(a.k)))) return rc;
         if ((rc = lin_fwd(WS(a.xn2), key(l, "1.module.attention.value_proj.linear.weight"), key(l, "1.module.attention.value_proj.linear.bias"), M, D, D, WS(a.v)))) return rc;
         if ((rc = lin_fwd(t->pe, key(l, "1.module.attention.pos_proj.linear.weight"), "", R, D, D, WS(a.P)))) return rc;
-        hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)((arows + 3) / 4)), dim3(256), 4 * 2 * dh * 4, s, WS(a.q), WS(a.k), WS(a.v), WS(a.P),
-                           Pp(key(l, "1.module.attention.u_bias")), Pp(key(l, "1.module.attention.v_bias")), WS(a.attn), WS(a.ctx), arows, T, Hh, dh, scale,
-                           p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
+        if (attn_gemm) {
+            hipLaunchKernelGGL(k_attn_qu_qv, grid1(MD), dim3(256), 0, s, WS(a.q), Pp(key(l, "1.module.attention.u_bias")), Pp(key(l, "1.module.attention.v_bias")),
+                               WS(oQu), WS(oQv), MD, D);
+            // S = (q + u) K^T -> attn buffer; Rm = (q + vb) P_h^T for all 2T - 1 relative positions
+            if ((rc = bgemm(WS(oQu), D, sTD, dh, WS(a.k), D, sTD, dh, T, T, dh, WS(a.attn), Tk, (long long)Hh * sTT, sTT))) return rc;
+            if ((rc = bgemm(WS(oQv), D, sTD, dh, WS(a.P), D, 0, dh, T, R, dh, WS(oRm), Rk, (long long)Hh * sTR, sTR))) return rc;
+            hipLaunchKernelGGL(k_attn_softmax, dim3((unsigned)((arows + 3) / 4)), dim3(256), 0, s, WS(a.attn), WS(oRm), p_at > 0.f ? WS(oAd) : (float *)nullptr, arows, T, Tk,
+                               Rk, scale, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
+            head_T(WS(a.v), WS(oHT));                                   // V^T per (line, head)
+            if ((rc = bgemm(p_at > 0.f ? WS(oAd) : WS(a.attn), Tk, (long long)Hh * sTT, sTT, WS(oHT), Tk, (long long)Hh * sHT, sHT, T, dh, Tk, WS(a.ctx), D, sTD, dh)))
+                return rc;
+        } else {
+            hipLaunchKernelGGL(k_attn_fwd, dim3((unsigned)((arows + 3) / 4)), dim3(256), 4 * 2 * dh * 4, s, WS(a.q), WS(a.k), WS(a.v), WS(a.P),
+                               Pp(key(l, "1.module.attention.u_bias")), Pp(key(l, "1.module.attention.v_bias")), WS(a.attn), WS(a.ctx), arows, T, Hh, dh, scale,
+                               p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
+        }
         if ((rc = lin_fwd(WS(a.ctx), key(l, "1.module.attention.out_proj.linear.weight"), key(l, "1.module.attention.out_proj.linear.bias"), M, D, D, WS(oDa)))) return rc;
         dropout(WS(oDa), MD, p_at, 16 * l + 5);
         hipLaunchKernelGGL(k_add3, grid1(MD), dim3(256), 0, s, WS(a.x2), WS(a.x1), WS(oDa), 1.0f, MD);
@@ -412,12 +452,43 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             if ((rc = lin_bwd(dob, WS(a.ctx), key(l, "1.module.attention.out_proj.linear.weight"), key(l, "1.module.attention.out_proj.linear.bias"), M, D, D, WS(oDc)))) return rc;   // d ctx
             float *du_part = WS(oDwide), *dvb_part = WS(oDwide) + MD;
             const float *ub = Pp(key(l, "1.module.attention.u_bias")), *vbp = Pp(key(l, "1.module.attention.v_bias"));
-            hipLaunchKernelGGL(k_attn_bwd_rows, dim3((unsigned)((arows + 3) / 4)), dim3(256), 4 * dh * 4, s, WS(oDc), WS(a.k), WS(a.v), WS(a.P), WS(a.attn), WS(oDsb),
-                               du_part, dvb_part, arows, T, Hh, dh, scale, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
-            hipLaunchKernelGGL(k_attn_bwd_cols, dim3((unsigned)((arows + 3) / 4)), dim3(256), 0, s, WS(oDc), WS(a.q), ub, WS(a.attn), WS(oDsb), WS(oDe), WS(oDa),
-                               arows, T, Hh, dh, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));            // d k -> oDe, d v -> oDa
+            if (attn_gemm) {
+                const unsigned site = (unsigned)(16 * l + 4);
+                const long long zTT = (long long)Hh * sTT, zHT = (long long)Hh * sHT;
+                hipLaunchKernelGGL(k_attn_qu_qv, grid1(MD), dim3(256), 0, s, WS(a.q), ub, vbp, WS(oQu), WS(oQv), MD, D);
+                // dA = dctx V^T, then ds (in place): oDsb
+                if ((rc = bgemm(WS(oDc), D, sTD, dh, WS(a.v), D, sTD, dh, T, T, dh, WS(oDsb), Tk, zTT, sTT))) return rc;
+                hipLaunchKernelGGL(k_attn_softmax_bwd, dim3((unsigned)((arows + 3) / 4)), dim3(256), 0, s, WS(oDsb), WS(a.attn), arows, T, Tk, scale, p_at,
+                                   (unsigned long long)seed, site);
+                // dV = drop(attn)^T dctx -> oDa
+                square_T(WS(a.attn), WS(oTT), true, p_at, site);
+                head_T(WS(oDc), WS(oHT));
+                if ((rc = bgemm(WS(oTT), Tk, zTT, sTT, WS(oHT), Tk, zHT, sHT, T, dh, Tk, WS(oDa), D, sTD, dh))) return rc;
+                // d(q + u) = ds K -> du_part
+                head_T(WS(a.k), WS(oHT));
+                if ((rc = bgemm(WS(oDsb), Tk, zTT, sTT, WS(oHT), Tk, zHT, sHT, T, dh, Tk, du_part, D, sTD, dh))) return rc;
+                // dK = ds^T (q + u) -> oDe
+                square_T(WS(oDsb), WS(oTT), false, 0.f, 0u);
+                head_T(WS(oQu), WS(oHT));
+                if ((rc = bgemm(WS(oTT), Tk, zTT, sTT, WS(oHT), Tk, zHT, sHT, T, dh, Tk, WS(oDe), D, sTD, dh))) return rc;
+                // dR = shift^-1(ds) -> oRm;  d(q + vb) = dR P_h -> dvb_part
+                hipLaunchKernelGGL(k_attn_unshift, dim3((unsigned)((arows + 3) / 4)), dim3(256), 0, s, WS(oDsb), WS(oRm), arows, T, Tk, Rk);
+                hipLaunchKernelGGL(k_btranspose, dim3(ceil_div(Rk, 32), ceil_div(dh, 32), Hh), dim3(256), 0, s, WS(a.P), WS(oPmT), R, dh, (long long)D, (long long)Rk, Rk, Hh, 0ll,
+                                   (long long)dh, (long long)dh * Rk, 0, 0.f, 0ull, 0u);
+                if ((rc = bgemm(WS(oRm), Rk, (long long)Hh * sTR, sTR, WS(oPmT), Rk, 0, (long long)dh * Rk, T, dh, Rk, dvb_part, D, sTD, dh))) return rc;
+                // dP_h = sum over the lines of dR^T (q + vb): per line into oLinePart [line][R][D], summed below
+                hipLaunchKernelGGL(k_btranspose, dim3(ceil_div(Tk, 32), ceil_div(R, 32), Z), dim3(256), 0, s, WS(oRm), WS(oDRT), T, R, (long long)Rk, (long long)Tk, Tk, 1, sTR, 0ll,
+                                   (long long)R * Tk, 0, 0.f, 0ull, 0u);
+                head_T(WS(oQv), WS(oHT));
+                if ((rc = bgemm(WS(oDRT), Tk, (long long)Hh * R * Tk, (long long)R * Tk, WS(oHT), Tk, zHT, sHT, R, dh, Tk, WS(oLinePart), D, (long long)R * D, dh))) return rc;
+            } else {
+                hipLaunchKernelGGL(k_attn_bwd_rows, dim3((unsigned)((arows + 3) / 4)), dim3(256), 4 * dh * 4, s, WS(oDc), WS(a.k), WS(a.v), WS(a.P), WS(a.attn), WS(oDsb),
+                                   du_part, dvb_part, arows, T, Hh, dh, scale, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
+                hipLaunchKernelGGL(k_attn_bwd_cols, dim3((unsigned)((arows + 3) / 4)), dim3(256), 0, s, WS(oDc), WS(a.q), ub, WS(a.attn), WS(oDsb), WS(oDe), WS(oDa),
+                                   arows, T, Hh, dh, p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));            // d k -> oDe, d v -> oDa
+                hipLaunchKernelGGL(k_attn_bwd_pos, dim3(ceil_div(R * Hh, 4), N), dim3(256), 0, s, WS(a.q), vbp, WS(oDsb), WS(oLinePart), N, T, Hh, dh);
+            }
             (void)hipMemsetAsync(WS(oDP), 0, (size_t)Rp * D * 4, s);
-            hipLaunchKernelGGL(k_attn_bwd_pos, dim3(ceil_div(R * Hh, 4), N), dim3(256), 0, s, WS(a.q), vbp, WS(oDsb), WS(oLinePart), N, T, Hh, dh);
             hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(R * D, 64)), dim3(256), 0, s, WS(oLinePart), WS(oDP), N, R * D, 0);
             colsum(du_part, nullptr, M, D, Gp(key(l, "1.module.attention.u_bias")), 0);
             colsum(dvb_part, nullptr, M, D, Gp(key(l, "1.module.attention.v_bias")), 0);
