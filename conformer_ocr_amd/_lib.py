@@ -51,6 +51,7 @@ SYMBOLS = {
     'cocr_train_get': (_I, [_P, C.c_char_p, _I, _P, C.c_int64, _P]),
     'cocr_train_adamw': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'cocr_train_end': (_I, [_P]),
+    'cocr_train_set_matmul': (_I, [_P, _I]),
     'cocr_train_grad_buffer': (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     'cocr_get_tensor': (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
     'cocr_preproc_width': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -23,6 +23,7 @@ struct TrainState {
     size_t ws_bytes = 0;
     float *pe = nullptr;                      // sinusoid rows for relative positions T-1 ... -(T-1), (2T-1, D)
     int peT = 0;
+    bool matmul_bf16 = false;                 // cocr_train_set_matmul: the Linear / pointwise-conv products on bf16-rounded operands (fp32 accumulate)
 };
 
 static void train_free(cocr_model *m) {
@@ -35,6 +36,13 @@ static void train_free(cocr_model *m) {
 }
 
 static bool train_is_buffer(const std::string &n) { return n.find("running_mean") != std::string::npos || n.find("running_var") != std::string::npos; }
+
+extern "C" int cocr_train_set_matmul(cocr_model *m, int bf16_operands) {
+    if (!m) return fail(COCR_EINVAL, "null argument");
+    if (!m->train) return fail(COCR_ESTATE, "cocr_train_begin first");
+    m->train->matmul_bf16 = bf16_operands != 0;
+    return COCR_OK;
+}
 
 extern "C" int cocr_train_begin(cocr_model *m) {
     if (!m) return fail(COCR_EINVAL, "null argument");
@@ -140,7 +148,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     // ---- shapes of the frontend stages
     std::vector<int> Ts(snum), Fs(snum);
     { int tt = W, f = H; for (int i = 0; i < snum; ++i) { tt = out_len1(tt); f = out_len1(f); Ts[i] = tt; Fs[i] = f; } }
-    const int T = Ts.back(), F = Fs.back(), M = N * T, Mp = round_up(M, 1024), R = 2 * T - 1, Rp = round_up(R, 1024);
+    const int T = Ts.back(), F = Fs.back(), M = N * T, Mp = round_up(M, 2048), R = 2 * T - 1, Rp = round_up(R, 2048);      // (row counts of split-K weight gradients: 32 or 64 x <= 32 splits)
     const int nclp = round_up(ncls, 4);
     // attention as batched exact-fp32 GEMMs (train_enc.hip.h) when d_head is a whole number of 32-wide k-chunks; else one wave per row
     const int Tk = round_up(T, 32), Rk = round_up(R, 32), Z = N * Hh;
@@ -176,10 +184,11 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     // backward scratch
     size_t big_rows = (size_t)M;
     for (int i = 0; i + 1 < snum; ++i) big_rows = std::max(big_rows, (size_t)N * Ts[i + 1] * Fs[i + 1]);
-    const size_t big_rows_p = (big_rows + 1023) / 1024 * 1024;
+    const size_t big_rows_p = (big_rows + 2047) / 2048 * 2048;
     const int wide = std::max(std::max(ff, 3 * D), std::max(C * F, std::max(2 * D, nclp)));
     const size_t tr_floats = std::max((size_t)wide * Mp, big_rows_p * (size_t)C);
     const size_t oTA = rsv(tr_floats), oTB = rsv(tr_floats), oTW = rsv((size_t)std::max(std::max((size_t)ff * D, (size_t)C * F * D), (size_t)std::max(C * C, D * nclp)) + 1024);
+    const size_t oBfA = rsv(t->matmul_bf16 ? tr_floats / 2 + 64 : 0), oBfW = rsv(t->matmul_bf16 ? tr_floats / 2 + 64 : 0);      // bf16 copies of a product's two operands
     const size_t oDa = rsv(MD), oDb = rsv(MD), oDc = rsv(MD), oDd = rsv(MD), oDe = rsv(MD), oDwide = rsv((size_t)M * std::max(ff, 2 * D)), oDwide2 = rsv((size_t)M * std::max(ff, 2 * D));
     const size_t oDsb = rsv((size_t)N * Hh * T * (attn_gemm ? Tk : T)), oDP = rsv((size_t)Rp * D);
     size_t oQu = 0, oQv = 0, oRm = 0, oAd = 0, oHT = 0, oTT = 0, oDRT = 0, oPmT = 0;
@@ -212,8 +221,20 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     auto key = [&](int l, const char *suffix) { snprintf(nb, sizeof nb, "encoder.layers.%d.sequential.%s", l, suffix); return std::string(nb); };
 
     // ---- primitives
+    // 'medium' matmul precision (cocr_train_set_matmul; the reference trains under torch.set_float32_matmul_precision('medium'),
+    // cli/train.py:252): both operands rounded to bf16, products on the bf16 matrix cores, fp32 accumulation and output
+    auto to_bf16 = [&](const float *in, size_t off, size_t n) -> const bf16_t * {
+        bf16_t *dst = reinterpret_cast<bf16_t *>(t->ws + off);
+        hipLaunchKernelGGL(k_f32_to_bf16, grid1((n + 3) / 4), dim3(256), 0, s, in, dst, (n + 3) / 4);
+        return dst;
+    };
     auto gemm = [&](const float *A, int lda, const float *Wt, int ldw, int Mr, int Nc, int Kr, float *out, int ldo, const float *bias) -> int {
         EpiStoreF32 e{out, ldo, bias, Nc};
+        if (t->matmul_bf16 && (lda & 7) == 0 && (ldw & 7) == 0 && (Kr & 7) == 0) {
+            const bf16_t *Ab = to_bf16(A, oBfA, (size_t)Mr * lda), *Wb = to_bf16(Wt, oBfW, (size_t)Nc * ldw);
+            GEMM_TRY(launch_gemm<bf16_t>(s, Ab, lda, Wb, ldw, Mr, Nc, Kr, e));
+            return COCR_OK;
+        }
         GEMM_TRY(launch_gemm<float>(s, A, lda, Wt, ldw, Mr, Nc, Kr, e));
         return COCR_OK;
     };
@@ -251,14 +272,19 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     };
     // dW += dY^T X, db += colsum(dY), dX = dY W   (dX null: not wanted).  dY (rows, Nc), X (rows, Kr)
     auto lin_bwd = [&](const float *dY, const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *dX) -> int {
-        const int splits = wg_splits(Nc, Kr), rp = round_up(rows, 32 * splits);
+        const int splits = wg_splits(Nc, Kr), rp = round_up(rows, (t->matmul_bf16 ? 64 : 32) * splits);
         int r;
         transpose(dY, WS(oTA), rows, Nc, rp);
         transpose(X, WS(oTB), rows, Kr, rp);
         if (splits == 1) {
             if ((r = gemm(WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, Gp(w), Kr, nullptr))) return r;
         } else {
-            GEMM_TRY(launch_gemm_splitk<float>(s, WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, splits, WS(oSplit)));
+            if (t->matmul_bf16) {
+                const bf16_t *Ab = to_bf16(WS(oTA), oBfA, (size_t)Nc * rp), *Wb = to_bf16(WS(oTB), oBfW, (size_t)Kr * rp);
+                GEMM_TRY(launch_gemm_splitk<bf16_t>(s, Ab, rp, Wb, rp, Nc, Kr, rp, splits, WS(oSplit)));
+            } else {
+                GEMM_TRY(launch_gemm_splitk<float>(s, WS(oTA), rp, WS(oTB), rp, Nc, Kr, rp, splits, WS(oSplit)));
+            }
             hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 64)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
         }
         if (!b.empty()) colsum(dY, nullptr, rows, Nc, Gp(b), 0);

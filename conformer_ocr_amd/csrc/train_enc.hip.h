@@ -35,6 +35,13 @@ __global__ static void k_add3(float *y, const float *a, const float *b, float al
 __global__ static void k_u8_to_f32(const uint8_t *in, float *out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i] * (1.0f / 255.0f);
 }
+// fp32 -> bf16 (round to nearest even), n a multiple of 4: the operands of the 'medium' matmul precision
+__global__ static void k_f32_to_bf16(const float *__restrict__ in, bf16_t *__restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(in)[i];
+        reinterpret_cast<bf16x4 *>(out)[i] = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    }
+}
 // out[c * ldo + r] = in[r * C + c]   (ldo >= R; the tail r in [R, ldo) must have been zeroed by the caller)
 __global__ static void k_transpose(const float *__restrict__ in, float *__restrict__ out, int R, int C, int ldo) {
     __shared__ float tile[32][33];

@@ -274,9 +274,14 @@ class HipRecognizer:
         return out
 
     # ---- training step of the whole network (include/cocr.h: cocr_train_*) ------------------------------
-    def train_begin(self) -> None:
-        """fp32 master copy of the loaded state (`load_state`) on the device, zeroed AdamW moments."""
+    def train_begin(self, matmul_precision: str = 'highest') -> None:
+        """fp32 master copy of the loaded state (`load_state`) on the device, zeroed AdamW moments.  matmul_precision: 'highest' (exact
+        fp32 products) or 'medium' (bf16-rounded operands, fp32 accumulation: torch.set_float32_matmul_precision('medium'), what the
+        reference's cli/train.py:252 sets)."""
+        if matmul_precision not in ('highest', 'medium'):
+            raise ValueError("matmul_precision must be 'highest' or 'medium'")
         _lib.check(self.lib.cocr_train_begin(self._h))
+        _lib.check(self.lib.cocr_train_set_matmul(self._h, int(matmul_precision == 'medium')))
 
     def train_step(self, lines: torch.Tensor, lens, targets, label_lens, dropout=(0.0, 0.0, 0.0, 0.0), seed: int = 0) -> float:
         """`RecognitionModel.training_step` without the optimizer (reference model.py:129-152): train-mode forward, summed CTC loss,

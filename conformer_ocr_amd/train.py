@@ -95,7 +95,7 @@ class Trainer:
     def __init__(self, net: PytorchRecognitionModel, lr: float = 1e-3, weight_decay: float = 1e-3, optimizer: str = 'AdamW', warmup: int = 0,
                  schedule: str = 'constant', gamma: float = 0.1, cos_t_max: int = 50, cos_min_lr: float = 1e-4, step_size: int = 10,
                  rop_factor: float = 0.1, rop_patience: int = 5, completed_epochs: int = 0, seed: int = 0, process_group=None,
-                 distributed: Optional[bool] = None):
+                 distributed: Optional[bool] = None, matmul_precision: str = 'highest'):
         if optimizer not in ('AdamW',):
             raise NotImplementedError(f'optimizer {optimizer}: only AdamW is built (the reference\'s default)')
         if schedule not in self.SCHEDULES:
@@ -119,7 +119,9 @@ class Trainer:
         from .engine import HipRecognizer
         self.engine = HipRecognizer(net.hparams_record, dev, 'fp32')
         self.engine.load_state({k: v for k, v in net.nn.state_dict().items()}, strict=True)
-        self.engine.train_begin()
+        # 'medium' = torch.set_float32_matmul_precision('medium') of the reference's cli/train.py:252 (bf16-rounded matmul operands);
+        # 'highest' (default) = exact fp32 products, what the gradient-parity tests are stated for
+        self.engine.train_begin(matmul_precision)
 
     def _lr_at_epoch(self, e: int) -> float:
         import math

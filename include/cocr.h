@@ -216,6 +216,10 @@ int cocr_train_step(cocr_model *m, const void *lines, int line_dtype, int N, int
 int cocr_train_get(cocr_model *m, const char *name, int kind, float *host_out, int64_t n_elems, void *stream);
 int cocr_train_adamw(cocr_model *m, float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
 int cocr_train_end(cocr_model *m);
+/* Matmul precision of the training step's Linear / pointwise-conv products (forward, input and weight gradients): 0 (default) exact fp32
+ * on the matrix cores; 1 = both operands rounded to bf16, fp32 accumulation -- what the reference trains under
+ * (torch.set_float32_matmul_precision('medium'), cli/train.py:252).  Parameters, activations, gradients and the optimizer stay fp32. */
+int cocr_train_set_matmul(cocr_model *m, int bf16_operands);
 /* The flat device gradient vector (float32, all parameters): a data-parallel job all-reduces it between cocr_train_step and cocr_train_adamw. */
 int cocr_train_grad_buffer(cocr_model *m, void **device_ptr, size_t *n_floats);
 

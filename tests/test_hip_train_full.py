@@ -154,6 +154,36 @@ def test_attention_as_batched_products_equals_the_row_kernels(monkeypatch):
     assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
 
 
+def test_medium_matmul_precision_stays_close_to_the_exact_step():
+    """matmul_precision 'medium' (the reference's torch.set_float32_matmul_precision('medium')): the Linear / pointwise-conv products of
+    the step on bf16-rounded operands with fp32 accumulation.  Loss within 1e-3 relative of the exact-fp32 step, every gradient within
+    10 % of the largest entry of its tensor (bf16 operand rounding through two blocks, forward and backward); bit-reproducible."""
+    c = CASES['cfg2x2']
+    hp = c['hp']()
+    state = synth.make_state_dict(hp, seed=c['seed'], decoder_gain=1.0)
+    image, lens = synth.make_lines(3, hp.height, 232, seed=9, widths=[232, 137, 200])
+    tg, tl = [5, 9, 9, 3, 17, 2, 2, 40], [4, 1, 3]
+    x = torch.from_numpy(image[:, 0]).cuda()
+    a = _engine(hp, state)
+    la = a.train_step(x, lens, tg, tl)
+    b = HipRecognizer(hp, torch.device('cuda', 0), 'fp32')
+    b.load_state(state)
+    b.train_begin('medium')
+    lb = b.train_step(x, lens, tg, tl)
+    assert lb != la and abs(la - lb) <= 1e-3 * abs(la), (la, lb)
+    names = [k for k, (shape, kind) in model_state_spec(hp).items() if kind == 'param']
+    scale = max(float(np.abs(a.train_grad(k)).max()) for k in names)        # (the key projection's bias has an exactly zero gradient: absolute floor)
+    worst = {}
+    for k in names:
+        ref, got = a.train_grad(k), b.train_grad(k)
+        err = float(np.abs(got - ref).max())
+        if err > 0.1 * float(np.abs(ref).max()) + 1e-3 * scale:
+            worst[k] = (err, float(np.abs(ref).max()))
+    assert not worst, dict(sorted(worst.items(), key=lambda kv: -kv[1][0])[:8])
+    g1 = b.train_grad('decoder.weight').copy()
+    assert b.train_step(x, lens, tg, tl) == lb and np.array_equal(g1, b.train_grad('decoder.weight'))
+
+
 def test_trainer_follows_the_reference_training_loop():
     """conformer_ocr_amd.train.Trainer = training_step + configure_optimizers + optimizer_step / lr_scheduler_step of the reference
     (model.py:147-152,238-321): warm-up exactly as the reference applies it, epoch-wise schedules equal to torch's schedulers, the loss

@@ -27,6 +27,7 @@ ap.add_argument('--width', type=int, default=1200)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--fit', type=int, default=0)
 ap.add_argument('--lr', type=float, default=1e-3)
+ap.add_argument('--matmul', default='highest', help="'highest' (exact fp32 products) or 'medium' (bf16-rounded operands, the reference's training setting)")
 args = ap.parse_args()
 kw = {'num_encoder_layers': args.layers} if args.layers else {}
 hp = synth.hparams(args.config, **kw)
@@ -38,7 +39,7 @@ net = net.to('cuda:0').eval()
 image, lens, texts, _ = synth.make_text_lines(args.batch, hp.height, args.width, seed=3)
 batch = {'image': torch.from_numpy(image).cuda(), 'seq_lens': torch.from_numpy(lens), 'target': torch.tensor([c for t in texts for c in t]),
          'target_lens': torch.tensor([len(t) for t in texts])}
-tr = Trainer(net, lr=args.lr, weight_decay=1e-2, warmup=10)
+tr = Trainer(net, lr=args.lr, weight_decay=1e-2, warmup=10, matmul_precision=args.matmul)
 out = {'config': args.config, 'layers': hp.num_encoder_layers, 'batch': args.batch, 'width': args.width}
 tr.training_step(batch)
 torch.cuda.synchronize()
