@@ -239,8 +239,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         return COCR_OK;
     };
     auto transpose = [&](const float *in, float *out, int Rr, int Cc, int ldo) {      // out (Cc, ldo) zero-padded beyond Rr
-        (void)hipMemsetAsync(out, 0, (size_t)Cc * ldo * 4, s);
-        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(Cc, 32), ceil_div(Rr, 32)), dim3(256), 0, s, in, out, Rr, Cc, ldo);
+        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(Cc, 32), ceil_div(ldo, 32)), dim3(256), 0, s, in, out, Rr, Cc, ldo);
     };
     // out_z (Mr x Nc, stride ldo) = A_z (Mr x Kr) W_z (Nc x Kr)^T over the Z = N * heads (line, head) batches: offsets per (line, head)
     auto bgemm = [&](const float *A, int lda, long long azb, long long azh, const float *Wm, int ldw, long long wzb, long long wzh, int Mr, int Nc, int Kr,

@@ -42,15 +42,14 @@ __global__ static void k_f32_to_bf16(const float *__restrict__ in, bf16_t *__res
         reinterpret_cast<bf16x4 *>(out)[i] = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
     }
 }
-// out[c * ldo + r] = in[r * C + c]   (ldo >= R; the tail r in [R, ldo) must have been zeroed by the caller)
+// out[c * ldo + r] = in[r * C + c] for r < R, 0 for R <= r < ldo (grid.y covers ldo: no separate clearing of the tail)
 __global__ static void k_transpose(const float *__restrict__ in, float *__restrict__ out, int R, int C, int ldo) {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8)
-        if (r0 + j < R && c0 + tx < C) tile[j][tx] = in[(size_t)(r0 + j) * C + c0 + tx];
+    for (int j = ty; j < 32; j += 8) tile[j][tx] = (r0 + j < R && c0 + tx < C) ? in[(size_t)(r0 + j) * C + c0 + tx] : 0.f;
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
-        if (c0 + j < C && r0 + tx < R) out[(size_t)(c0 + j) * ldo + r0 + tx] = tile[tx][j];
+        if (c0 + j < C && r0 + tx < ldo) out[(size_t)(c0 + j) * ldo + r0 + tx] = tile[tx][j];
 }
 // out (M, ldo) <- in (M, C), columns C..ldo-1 zero
 __global__ static void k_pad_cols(const float *__restrict__ in, float *__restrict__ out, int M, int C, int ldo) {
