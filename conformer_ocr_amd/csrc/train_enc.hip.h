@@ -473,15 +473,26 @@ __global__ static void k_bn_bwd(const float *__restrict__ dy, const float *__res
 // conv.0: Z1[n, t1, f1, c] = relu(b0[c] + sum_{dt,df} w0[c, dt, df] X[n, 2 f1 + df - 1, 2 t1 + dt - 1])    (X (N, H, W); zero outside)
 __global__ static void k_conv0_fwd(const float *__restrict__ X, const float *__restrict__ w0, const float *__restrict__ b0, float *__restrict__ Z1,
                                    int N, int H, int W, int T1, int F1, int C) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * T1 * F1 * C; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C), f = (int)((i / C) % F1), t = (int)((i / ((size_t)C * F1)) % T1), n = (int)(i / ((size_t)C * F1 * T1));
-        float acc = b0[c];
+    // a thread = one position x four consecutive channels (one 16-byte store; the nine pixels are shared by the 64 lanes of a position
+    // group; 32-bit index arithmetic, once per four outputs).  C % 4 == 0 (checked by cocr_create: multiples of 8).
+    const unsigned cq = (unsigned)C >> 2, npos = (unsigned)N * T1 * F1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)npos * cq; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned pos = (unsigned)(i / cq), c = 4 * (unsigned)(i - (size_t)pos * cq);
+        const unsigned f = pos % F1, tn = pos / F1, t = tn % T1, n = tn / T1;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(b0 + c);
+        const float *xb = X + (size_t)n * H * W;
+#pragma unroll
         for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
             for (int df = 0; df < 3; ++df) {
-                const int col = 2 * t + dt - 1, row = 2 * f + df - 1;
-                if (col >= 0 && col < W && row >= 0 && row < H) acc = fmaf(w0[c * 9 + dt * 3 + df], X[((size_t)n * H + row) * W + col], acc);
+                const int col = 2 * (int)t + dt - 1, row = 2 * (int)f + df - 1;
+                if (col >= 0 && col < W && row >= 0 && row < H) {
+                    const float x = xb[(size_t)row * W + col];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w0[(c + q) * 9 + dt * 3 + df], x, acc[q]);
+                }
             }
-        Z1[i] = fmaxf(acc, 0.f);
+        *reinterpret_cast<f32x4 *>(Z1 + (size_t)pos * C + c) = (f32x4){fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
     }
 }
 // d w0[c, tap] and d b0[c] partial sums over chunks of positions (dZ1 already masked by the ReLU): thread = c, block.y = chunk
@@ -492,8 +503,9 @@ __global__ static void k_conv0_bwd_w(const float *__restrict__ dZ1, const float 
     const size_t npos = (size_t)N * T1 * F1, p0 = (size_t)chunk * COCR_CV_POS, p1 = min(npos, p0 + COCR_CV_POS);
     float acc[10];
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    for (size_t pos = p0; pos < p1; ++pos) {
-        const int f = (int)(pos % F1), t = (int)((pos / F1) % T1), n = (int)(pos / ((size_t)F1 * T1));
+    int f = (int)(p0 % F1), t = (int)((p0 / F1) % T1), n = (int)(p0 / ((size_t)F1 * T1));      // (kept by increments: no division per position)
+    for (size_t pos = p0; pos < p1; ++pos, ++f) {
+        if (f == F1) { f = 0; if (++t == T1) { t = 0; ++n; } }
         const float d = dZ1[pos * C + c];
         acc[9] += d;
         for (int dt = 0; dt < 3; ++dt)
@@ -540,8 +552,9 @@ __global__ static void k_dw3_bwd_w(const float *__restrict__ dZo, const float *_
     const size_t npos = (size_t)N * To * Fo, p0 = (size_t)chunk * COCR_CV_POS, p1 = min(npos, p0 + COCR_CV_POS);
     float acc[10];
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    for (size_t pos = p0; pos < p1; ++pos) {
-        const int f = (int)(pos % Fo), t = (int)((pos / Fo) % To), n = (int)(pos / ((size_t)Fo * To));
+    int f = (int)(p0 % Fo), t = (int)((p0 / Fo) % To), n = (int)(p0 / ((size_t)Fo * To));
+    for (size_t pos = p0; pos < p1; ++pos, ++f) {
+        if (f == Fo) { f = 0; if (++t == To) { t = 0; ++n; } }
         const float d = dZo[pos * C + c];
         acc[9] += d;
         for (int dt = 0; dt < 3; ++dt)
