@@ -1402,7 +1402,10 @@ extern "C" int cocr_ctc_beam(cocr_model *m, const float *logits, int N, int T, i
         hipLaunchKernelGGL(ctc_beam_rank_kernel, dim3(N * T), dim3(256), 0, s, logits, T, ncls, m->d_lens_cur, K, rec);
 #define COCR_BEAM_WALK(SL)                                                                                                                          \
     {                                                                                                                                               \
-        if (bp_in_lds) HIP_TRY(raise_lds_limit((const void *)ctc_beam_walk_kernel<SL>, dyn));                                                       \
+        if (bp_in_lds && dyn > 48 * 1024) {      /* (the kernel also has ~12 KB of static LDS: the limit raised for the dynamic part stays below 160 KB - static) */ \
+            static bool raised = false;                                                                                                             \
+            if (!raised) { HIP_TRY(hipFuncSetAttribute((const void *)ctc_beam_walk_kernel<SL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); raised = true; } \
+        } \
         hipLaunchKernelGGL(ctc_beam_walk_kernel<SL>, dim3(N), dim3(256), bp_in_lds ? dyn : 0, s, logits, T, ncls, m->d_lens_cur, beam, K, labels, starts, \
                            ends, conf, counts, max_per_line, rec, bp, bp_in_lds, m->stamps ? m->stamps + 240 : nullptr);                            \
     }

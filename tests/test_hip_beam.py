@@ -70,10 +70,12 @@ def test_beam_zero_length_and_model_attribute(case):
         assert [x[0] for x in recs[n]] == [x[0] for x in want]
 
 
-@pytest.mark.parametrize('C,T,beam,scale', [(128, 300, 16, 2.5), (128, 300, 16, 0.3), (200, 120, 32, 1.5), (17, 90, 16, 1.0), (3, 50, 8, 1.0)])
+@pytest.mark.parametrize('C,T,beam,scale', [(128, 300, 16, 2.5), (128, 300, 16, 0.3), (200, 120, 32, 1.5), (17, 90, 16, 1.0), (3, 50, 8, 1.0),
+                                              (7, 500, 32, 1.0), (40, 1500, 16, 2.0), (256, 40, 16, 2.0), (2, 30, 4, 1.0)])
 def test_beam_pruned_equals_exhaustive(C, T, beam, scale, monkeypatch):
-    """cocr_ctc_beam ranks beam x (beam + 1) candidates per frame (ctc_beam2_kernel); COCR_BEAM_REF=1 selects the kernel that
-    ranks all beam x C of them.  Every output field must agree exactly (same arithmetic, same tie rules), on peaked and on
+    """cocr_ctc_beam ranks a static pruned candidate set per frame (ctc_beam_rank_kernel + ctc_beam_walk_kernel); COCR_BEAM_REF=1 selects
+    the kernel that ranks all beam x C of them.  (7, 500, 32): back-pointers in more than 64 KB of LDS; (40, 1500, 16): in global memory;
+    256 and 2 classes: the ends of the fast path's range.  Every output field must agree exactly (same arithmetic, same tie rules), on peaked and on
     nearly flat logits (many near-ties), full-length and ragged lines."""
     from conformer_ocr_amd.engine import HipRecognizer
     from conformer_ocr_amd.spec import HParams
