@@ -127,15 +127,18 @@ def test_dropout_is_reproducible_and_changes_the_step():
         assert abs(fd - g1[j]) <= 5e-2 * max(1.0, abs(g1[j])), (j, fd, g1[j])
 
 
-def test_attention_as_batched_products_equals_the_row_kernels(monkeypatch):
+@pytest.mark.parametrize('n,w', [(3, 232), (1, 70), (4, 520)])
+def test_attention_as_batched_products_equals_the_row_kernels(n, w, monkeypatch):
     """The training step's attention runs as batched exact-fp32 MFMA products when d_head is a multiple of 32 (cfg2: 4 heads of 64),
     else (and with COCR_TRAIN_ATTN_NAIVE=1) one wave per query / key row.  Same dropout masks (a function of seed, site and element):
     loss and EVERY gradient of the two forms agree to fp32 summation order, with all four dropout sites active."""
     c = CASES['cfg2x2']
     hp = c['hp']()
     state = synth.make_state_dict(hp, seed=c['seed'], decoder_gain=1.0)
-    image, lens = synth.make_lines(3, hp.height, 232, seed=9, widths=[232, 137, 200])
-    tg, tl = [5, 9, 9, 3, 17, 2, 2, 40], [4, 1, 3]
+    widths = [w, max(9, w * 3 // 5), max(9, w - 31), w][:n]
+    image, lens = synth.make_lines(n, hp.height, w, seed=9, widths=widths)
+    tl = [4, 1, 3, 2][:n]
+    tg = [5, 9, 9, 3, 17, 2, 2, 40, 7, 7][:sum(tl)]
     x = torch.from_numpy(image[:, 0]).cuda()
     p = (0.1, 0.1, 0.1, 0.1)
     a = _engine(hp, state)
@@ -149,7 +152,7 @@ def test_attention_as_batched_products_equals_the_row_kernels(monkeypatch):
     for k, g in ga.items():
         ref = b.train_grad(k)
         err = float(np.abs(g - ref).max())
-        if not err <= 1e-4 * float(np.abs(ref).max()) + 1e-6:
+        if not err <= 1e-4 * float(np.abs(ref).max()) + 1e-5:      # (the key projection's bias: an exactly zero gradient, rounding noise only)
             bad[k] = (err, float(np.abs(ref).max()))
     assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
 
