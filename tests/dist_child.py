@@ -25,12 +25,17 @@ def main():
     image, lens, _, _ = synth.make_text_lines(4, hp.height, 400, seed=11)
     x = torch.from_numpy(image[:, 0]).to(dev)
     out = {'rank': rank, 'world': world}
-    for dtype in ('bf16', 'fp32'):
-        b = HipRecognizer(hp, dev, dtype)
+    # 'padded': the reference's default width (144) -- in bf16 the blob that travels is the zero-padded 256-wide layout
+    for dtype in ('bf16', 'fp32', 'padded'):
+        if dtype == 'padded':
+            hp, dtype_ = synth.hparams('cfg1', num_encoder_layers=2), 'bf16'
+        else:
+            dtype_ = dtype
+        b = HipRecognizer(hp, dev, dtype_)
         b.finalize_empty()
         a = None
         if rank == 0:
-            a = HipRecognizer(hp, dev, dtype)
+            a = HipRecognizer(hp, dev, dtype_)
             a.load_state(synth.make_state_dict(hp, seed=3, decoder_gain=1.0, style='text'))
             a.finalize()
         broadcast_weights(b, src=0, source=a)

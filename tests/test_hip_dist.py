@@ -30,7 +30,7 @@ def test_nccl_broadcast_start_up_in_a_fresh_process():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert out['world'] == 1 and out['shard'] == [0, 1, 2, 3, 4]
-    for dtype in ('bf16', 'fp32'):
+    for dtype in ('bf16', 'fp32', 'padded'):
         o = out[dtype]
         assert o['finite'] and o['same_on_all_ranks'] and o['bit_equal_to_direct_finalize'], o
     assert out['train']['loss1'] < out['train']['loss0'] and out['train']['grad_floats'] > 10000      # all-reduced flat gradient, AdamW
