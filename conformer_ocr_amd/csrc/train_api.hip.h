@@ -46,7 +46,6 @@ extern "C" int cocr_train_set_matmul(cocr_model *m, int bf16_operands) {
 
 extern "C" int cocr_train_begin(cocr_model *m) {
     if (!m) return fail(COCR_EINVAL, "null argument");
-    if (m->snum < 2) return fail(COCR_EUNSUPPORTED, "the training step covers subsampling_factor >= 4 (factor 2 has no depthwise / pointwise stage)");
     HIP_TRY(hipSetDevice(m->device));
     train_free(m);
     TrainState *t = new TrainState();
@@ -538,7 +537,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     dropout(dx, MD, p_in, 1);
     if ((rc = lin_bwd(dx, WS(oZt), "encoder.conv_subsample.out.0.weight", "encoder.conv_subsample.out.0.bias", M, D, C * F, WS(oZg)))) return rc;
     {
-        float *dz3 = WS(oZa), *dz2 = WS(oZb);
+        float *dz3 = snum == 1 ? WS(oZ1g) : WS(oZa), *dz2 = WS(oZb);      // (factor 2: the flattened tensor IS conv.0's output)
         hipLaunchKernelGGL(k_tfc_to_tcf, grid1((size_t)M * F * C), dim3(256), 0, s, WS(oZg), dz3, (size_t)M, F, C, 1);
         for (int i = snum - 2, idx = 2 + 3 * (snum - 2); i >= 0; --i, idx -= 3) {
             const size_t rows = (size_t)N * Ts[i + 1] * Fs[i + 1];

@@ -23,6 +23,8 @@ def _engine(hp, state):
 CASES = {
     # the reference's own fixture configuration (tiny_train.npz), ragged widths
     'tiny': dict(hp=lambda: synth.hparams('tiny'), seed=4321, n=3, W=64, widths=[64, 37, 50], targets=[[3, 1, 4], [1, 5], [9, 2, 6, 5]], gain=1.0),
+    # subsampling factor 2 (conv.0 + ReLU only in front of the output linear)
+    'tiny2': dict(hp=lambda: synth.hparams('tiny', subsampling_factor=2), seed=78, n=2, W=40, widths=[40, 27], targets=[[2, 7, 1], [4]], gain=1.0),
     # subsampling factor 8 (one more depthwise / pointwise frontend stage)
     'tiny8': dict(hp=lambda: synth.hparams('tiny', subsampling_factor=8, height=32), seed=77, n=2, W=96, widths=[96, 61], targets=[[2, 7], [4]], gain=1.0),
     # the metric model's shapes (D=256, 4 heads of 64, 256 conv channels, kernel 31), two blocks, short lines
@@ -30,7 +32,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny8', 'cfg2x2'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny2', 'tiny8', 'cfg2x2'])
 def test_every_gradient_against_autograd_of_the_oracle(name):
     c = CASES[name]
     hp = c['hp']()
