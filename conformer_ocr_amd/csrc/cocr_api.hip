@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cocr.h"
@@ -1265,8 +1266,9 @@ static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N
     //     logits out (~20 MB at 32 x 96 x 1200 f32: a few microseconds) instead of ~40 host-side launches.
     const int Tn = cocr_out_len(W, m->hp.subsampling_factor);
     const bool shape_ready = m->vtN == N && m->vtT == Tn;      // the first call of a shape runs plain: one-time attribute / zeroing work
-    auto same = [&](const cocr_model::GraphEntry &g) { return g.lines == lines && g.logits == logits && g.N == N && g.W == W && g.dtype == line_dtype && g.s == s; };
-    auto same_shape = [&](const cocr_model::GraphEntry &g) { return g.lines == nullptr && g.N == N && g.W == W && g.dtype == line_dtype && g.s == s; };
+    // (the stream is not part of either key: an instantiated graph launches on any stream, and one model serves one stream at a time anyway)
+    auto same = [&](const cocr_model::GraphEntry &g) { return g.lines == lines && g.logits == logits && g.N == N && g.W == W && g.dtype == line_dtype; };
+    auto same_shape = [&](const cocr_model::GraphEntry &g) { return g.lines == nullptr && g.N == N && g.W == W && g.dtype == line_dtype; };
     auto capture = [&](const void *in, float *out, hipGraphExec_t *exec) -> int {
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1309,6 +1311,33 @@ static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N
     if ((rc = capture(m->g_lines, m->g_logits, &exec))) return rc;
     m->graphs.push_back({nullptr, nullptr, N, W, line_dtype, s, exec});
     return staged_launch(exec);
+}
+
+// ------------------------------------------------------------------------------------ host-side collation
+extern "C" int cocr_collate_lines(const void *const *lines, const int32_t *widths, int N, int H, int elem_size, void *dst, int W, int threads) {
+    if (N < 0 || H <= 0 || W <= 0 || (elem_size != 1 && elem_size != 4)) return fail(COCR_EINVAL, "collate: bad shape or element size");
+    if (N == 0) return COCR_OK;
+    if (!lines || !widths || !dst) return fail(COCR_EINVAL, "collate: null argument");
+    for (int i = 0; i < N; ++i)
+        if (!lines[i] || widths[i] < 0 || widths[i] > W) return fail(COCR_EINVAL, "collate: line %d is %d wide, the batch %d", i, widths[i], W);
+    const long rows = (long)N * H;
+    auto span = [=](long r0, long r1) {
+        for (long r = r0; r < r1; ++r) {
+            const int i = (int)(r / H), y = (int)(r % H);
+            const size_t wb = (size_t)widths[i] * elem_size, Wb = (size_t)W * elem_size;
+            char *d = (char *)dst + (size_t)r * Wb;
+            memcpy(d, (const char *)lines[i] + (size_t)y * wb, wb);
+            memset(d + wb, 0, Wb - wb);
+        }
+    };
+    const int nt = (int)std::max(1L, std::min<long>(std::min(threads, 64), rows / 64));
+    if (nt <= 1) { span(0, rows); return COCR_OK; }
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    for (int t = 1; t < nt; ++t) pool.emplace_back(span, rows * t / nt, rows * (t + 1) / nt);
+    span(0, rows / nt);
+    for (auto &t : pool) t.join();
+    return COCR_OK;
 }
 
 // ------------------------------------------------------------------------------------ CTC

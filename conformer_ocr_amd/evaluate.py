@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -145,16 +147,172 @@ def collate(lines: Sequence[np.ndarray], idx: Sequence[int], width: int) -> Tupl
     return torch.from_numpy(batch), torch.from_numpy(lens)
 
 
+class _PinnedPool:
+    """Pinned (N,1,H,W) staging tensors, kept across calls: pinning host memory costs milliseconds per allocation (a fresh
+    `pin_memory()` per batch held the whole loop at ~2 k lines/s), so a shape's buffers are allocated once, handed out through a queue
+    and handed back together with the event of the copy that read them.  Least recently used shapes are dropped beyond `cap` bytes."""
+
+    def __init__(self, cap: int = 2 << 30):
+        import queue
+        import threading
+        self._queue = queue.Queue
+        self.lock = threading.Lock()
+        self.shapes: Dict[tuple, list] = {}         # key -> [free queue, buffers allocated, bytes per buffer]
+        self.cap = cap
+
+    def take(self, key: tuple, depth: int) -> torch.Tensor:
+        with self.lock:
+            ent = self.shapes.pop(key, None)
+            if ent is None:
+                n, h, w, dtype = key
+                ent = [self._queue(), 0, n * h * w * (1 if dtype == torch.uint8 else 4)]
+            self.shapes[key] = ent                   # most recently used last
+            grow = ent[0].empty() and ent[1] < depth
+            if grow:
+                ent[1] += 1
+                total = sum(e[1] * e[2] for e in self.shapes.values())
+                for k in list(self.shapes):
+                    if total <= self.cap or k == key:
+                        break
+                    e = self.shapes.pop(k)           # its tensors are freed once their last holders let go
+                    total -= e[1] * e[2]
+        if grow:
+            n, h, w, dtype = key
+            return torch.empty((n, 1, h, w), dtype=dtype).pin_memory()
+        buf, copied = ent[0].get()
+        if copied is not None:
+            copied.synchronize()
+        return buf
+
+    def give(self, key: tuple, buf: torch.Tensor, copied) -> None:
+        with self.lock:
+            ent = self.shapes.get(key)
+        if ent is not None:
+            ent[0].put((buf, copied))
+
+
+_PINNED = _PinnedPool()
+
+
+class _Stager:
+    """Producer side of the pipelined loops: a thread collates batch after batch into pinned staging buffers
+    (`cocr_collate_lines`: native row copies on a few host threads, outside the GIL) while the caller's thread uploads, launches and
+    reads back the batches before.  uint8 lines stay uint8 (the forward ingests them as they are: pixel / 255), anything else becomes
+    float32.  Iterating yields (line indices, pinned batch, widths, key); the consumer calls `release(key, batch, copy event)`."""
+
+    def __init__(self, lines: Sequence[np.ndarray], batches: Sequence[Tuple[int, List[int]]], order: Iterable[int], depth: int,
+                 threads: int = 4, ahead: int = 2):
+        import queue
+        import threading
+        from . import _lib
+        self.lib = _lib.load()
+        self.lines, self.batches, self.order = lines, batches, list(order)
+        self.depth = max(ahead + 2, depth + ahead + 1)
+        self.threads = max(1, min(threads, (os.cpu_count() or 2) // 2))
+        self.ready = queue.Queue(maxsize=ahead)
+        self.stop = False
+        self.thread = threading.Thread(target=self._produce, name='cocr-collate', daemon=True)
+        self.thread.start()
+
+    def _collate(self, idx: Sequence[int], width: int):
+        import ctypes as C
+        lines = self.lines
+        u8 = all(lines[i].dtype == np.uint8 for i in idx)
+        dtype, npdt = (torch.uint8, np.uint8) if u8 else (torch.float32, np.float32)
+        src = [np.ascontiguousarray(lines[i], dtype=npdt) for i in idx]          # no copy for contiguous lines of that type
+        h = src[0].shape[0]
+        for a in src:
+            if a.ndim != 2 or a.shape[0] != h or a.shape[1] > width:
+                raise ValueError(f'line of shape {a.shape} in a batch of height {h}, width {width}')
+        key = (len(idx), h, width, dtype)
+        buf = _PINNED.take(key, self.depth)
+        widths = np.array([a.shape[1] for a in src], dtype=np.int32)
+        ptrs = (C.c_void_p * len(src))(*[a.__array_interface__['data'][0] for a in src])
+        rc = self.lib.cocr_collate_lines(ptrs, widths.ctypes.data_as(C.POINTER(C.c_int32)), len(src), h, 1 if u8 else 4,
+                                         C.c_void_p(buf.data_ptr()), width, self.threads)
+        if rc:
+            raise RuntimeError((self.lib.cocr_last_error() or b'').decode())
+        return idx, buf, torch.from_numpy(widths.astype(np.int64)), key
+
+    def _produce(self):
+        try:
+            for b in self.order:
+                if self.stop:
+                    return
+                width, idx = self.batches[b]
+                self.ready.put(self._collate(idx, width))
+            self.ready.put(None)
+        except BaseException as e:               # handed to the consumer
+            self.ready.put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.ready.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    @staticmethod
+    def release(key: tuple, buf: torch.Tensor, copied) -> None:
+        _PINNED.give(key, buf, copied)
+
+    def close(self) -> None:
+        self.stop = True
+        while self.thread.is_alive():            # unblock a producer waiting on a full queue
+            try:
+                item = self.ready.get(timeout=0.05)
+                if isinstance(item, tuple):
+                    _PINNED.give(item[3], item[1], None)
+            except Exception:
+                pass
+        self.thread.join()
+
+
 def recognize(net, lines: Sequence[np.ndarray], batch_size: int = 32, edge: int = 200, rank: int = 0, world: int = 1,
-              device: str = 'cuda:0', pipelined: bool = True) -> Dict[int, str]:
+              device: str = 'cuda:0', pipelined: bool = True, streams: int = 1) -> Dict[int, str]:
     """Strings for this rank's share of `lines` (H x w float arrays in [0,1]); keys are line indices.
 
     pipelined: batch k+1 is collated, copied host->device (pinned staging buffer, side stream) and enqueued while batch k is
     computed; batch k's label records are read back while batch k+1 runs (the reference's loop, cli/test.py:185-212, is
-    serial: copy, forward, decode, next).  Same strings either way."""
+    serial: copy, forward, decode, next).  streams > 1: that many batches in flight, each on a stream and a packed copy of the model
+    of its own (`net.engine_pool`): one batch's kernels leave a third of the chip idle, four fill it (bench.py's `value` against
+    `value_streams1`).  Same strings every way: a line's logits depend on its padded batch only."""
     batches = make_batches([l.shape[1] for l in lines], batch_size, edge)
     out: Dict[int, str] = {}
     dev = torch.device(device)
+    from .ctc_decoder import BeamDecoder, GreedyDecoder
+    if pipelined and streams > 1 and isinstance(net.ctc_decoder, (GreedyDecoder, BeamDecoder)):
+        engines = net.engine_pool(streams, dev)
+        cuda_streams = net.pool_streams(streams, dev)
+        beam = net.ctc_decoder.beam_size if isinstance(net.ctc_decoder, BeamDecoder) else 0
+        inflight: List[tuple] = []
+
+        def finish(item):
+            idx, k, handle, _keep = item
+            for i, locs in zip(idx, engines[k].collect(handle)):
+                out[i] = ''.join(x[0] for x in net.codec.decode(locs))
+        stager = _Stager(lines, batches, shard_batches(len(batches), rank, world), depth=streams)
+        try:
+            for j, (idx, staged, lens, key) in enumerate(stager):
+                k = j % streams
+                eng = engines[k]
+                with torch.cuda.stream(cuda_streams[k]):
+                    d_im = staged.to(dev, non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record()
+                    stager.release(key, staged, copied)
+                    lg, ol = eng.forward(d_im.squeeze(1), lens.numpy())
+                    handle = (eng._decode_async(eng.lib.cocr_ctc_beam, lg, ol, extra=(int(beam),)) if beam else eng.ctc_greedy_async(lg, ol))
+                inflight.append((idx, k, handle, (d_im, lg)))
+                if len(inflight) >= streams:
+                    finish(inflight.pop(0))
+            for item in inflight:
+                finish(item)
+        finally:
+            stager.close()
+        return out
     if not pipelined:
         for b in shard_batches(len(batches), rank, world):
             width, idx = batches[b]
@@ -163,26 +321,28 @@ def recognize(net, lines: Sequence[np.ndarray], batch_size: int = 32, edge: int 
                 out[i] = s
         return out
     copy_stream = torch.cuda.Stream(dev)
+    stager = _Stager(lines, batches, shard_batches(len(batches), rank, world), depth=2)
     pending = None
-    for b in shard_batches(len(batches), rank, world):
-        width, idx = batches[b]
-        im, lens = collate(lines, idx, width)
-        staged = im.pin_memory()
-        with torch.cuda.stream(copy_stream):
-            d_im = staged.to(dev, non_blocking=True)
-            arrived = torch.cuda.Event()
-            arrived.record(copy_stream)
-        main = torch.cuda.current_stream(dev)
-        main.wait_event(arrived)
-        handle = net.predict_string_async(d_im, lens)
-        d_im.record_stream(main)
+    try:
+        for idx, staged, lens, key in stager:
+            with torch.cuda.stream(copy_stream):
+                d_im = staged.to(dev, non_blocking=True)
+                arrived = torch.cuda.Event()
+                arrived.record(copy_stream)
+            stager.release(key, staged, arrived)
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(arrived)
+            handle = net.predict_string_async(d_im, lens)
+            d_im.record_stream(main)
+            if pending is not None:
+                for i, s in zip(pending[0], net.collect_strings(pending[1])):
+                    out[i] = s
+            pending = (idx, handle)
         if pending is not None:
             for i, s in zip(pending[0], net.collect_strings(pending[1])):
                 out[i] = s
-        pending = (idx, handle, staged)
-    if pending is not None:
-        for i, s in zip(pending[0], net.collect_strings(pending[1])):
-            out[i] = s
+    finally:
+        stager.close()
     return out
 
 

@@ -159,6 +159,32 @@ class PytorchRecognitionModel(nn.Module):
             self._engine, self._engine_sig = eng, sig
         return self._engine
 
+    def engine_pool(self, n: int, device: Optional[torch.device] = None) -> List[HipRecognizer]:
+        """`n` packed copies of the device model for callers that keep several batches in flight, one per stream
+        (conformer_ocr_amd/evaluate.py `recognize(..., streams=n)`): each has its own workspace and captured launch sequences; the
+        row-chain kernels run their throughput form (96-row blocks: every weight byte streamed once per block -- with several batches
+        in flight the chip is full anyway).  Rebuilt when the parameters change, like `engine()`."""
+        eng0 = self.engine(device)
+        if getattr(self, '_pool_sig', None) != self._engine_sig:
+            self._pool, self._pool_sig = [], self._engine_sig
+        while len(self._pool) < n:
+            eng = HipRecognizer(self.hparams_record, eng0.device, self.compute_dtype)
+            eng.load_state({k: v for k, v in self.nn.state_dict().items()}, strict=True)
+            eng.finalize()
+            eng.set_chain_rows(0)
+            eng.set_graph(True)
+            self._pool.append(eng)
+        return self._pool[:n]
+
+    def pool_streams(self, n: int, device: Optional[torch.device] = None) -> List['torch.cuda.Stream']:
+        """The streams the copies of `engine_pool` run on: kept, so that repeated loops queue on the same few hardware queues."""
+        dev = self.engine(device).device
+        if getattr(self, '_pool_streams_dev', None) != dev:
+            self._pool_streams_list, self._pool_streams_dev = [], dev
+        while len(self._pool_streams_list) < n:
+            self._pool_streams_list.append(torch.cuda.Stream(dev))
+        return self._pool_streams_list[:n]
+
     def adopt_engine(self, eng: HipRecognizer) -> None:
         """Use an already packed device model (e.g. one whose weights arrived by RCCL broadcast)."""
         self._engine = eng

@@ -96,6 +96,13 @@ int cocr_blob_import(cocr_model *m, const void *src_device, size_t bytes, void *
 /* calc_length (convolution.py:240-247) with k=3, s=2, p=1 repeated log2(subsampling_factor) times. */
 int32_t cocr_out_len(int32_t in_len, int32_t subsampling_factor);
 
+/* Host-side collation of a line batch: what kraken's `collate_sequences` does for the reference's loaders (cli/test.py:186-189, the
+ * `DataLoader(..., collate_fn=collate_sequences)`): N lines of H rows each, line i `widths[i]` elements wide and C-contiguous, are
+ * copied left-aligned into the (N,H,W) batch `dst` and the rest of every row is zeroed.  Plain host memory on both sides (dst is
+ * typically a pinned staging buffer the caller uploads with one copy); elem_size 1 (uint8 lines) or 4 (float32); the rows are split
+ * over `threads` host threads (<= 1: the calling thread alone).  No GPU call is made. */
+int cocr_collate_lines(const void *const *lines, const int32_t *widths, int N, int H, int elem_size, void *dst, int W, int threads);
+
 /* Pre-allocates workspace for batches up to N lines of width W (otherwise cocr_forward grows it on
  * demand, which synchronises and must not happen inside a stream capture). */
 int cocr_reserve(cocr_model *m, int N, int W);

@@ -51,8 +51,11 @@ def test_pipelined_loop_equals_serial_loop(case):
     net = _net(hp, state, 'fp32')
     serial = recognize(net, lines, batch_size=4, pipelined=False)
     assert recognize(net, lines, batch_size=4, pipelined=True) == serial
+    assert recognize(net, lines, batch_size=4, streams=3) == serial          # three batches in flight on three streams / model copies
     net.ctc_decoder = BeamDecoder(4)
-    assert recognize(net, lines, batch_size=4, pipelined=True) == recognize(net, lines, batch_size=4, pipelined=False)
+    beam_serial = recognize(net, lines, batch_size=4, pipelined=False)
+    assert recognize(net, lines, batch_size=4, pipelined=True) == beam_serial
+    assert recognize(net, lines, batch_size=4, streams=4) == beam_serial
     from oracle.ctc_ref import greedy_decoder as host_greedy
     net.ctc_decoder = host_greedy                     # any callable (ncls, T) -> records: the reference's host loop
     assert recognize(net, lines, batch_size=4, pipelined=True) == serial

@@ -38,6 +38,33 @@ def test_out_len_entry_point_matches_calc_length():
         assert lib.cocr_out_len(w, f) == want
 
 
+@pytest.mark.parametrize('dtype', [np.uint8, np.float32])
+@pytest.mark.parametrize('threads', [1, 4])
+def test_native_collation_equals_the_python_loop(dtype, threads):
+    """cocr_collate_lines = evaluate.collate (left-aligned lines, zero padding), no GPU involved."""
+    import ctypes as C
+    from conformer_ocr_amd.evaluate import collate
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for N, H, W in [(1, 3, 5), (7, 16, 130), (32, 96, 400)]:
+        widths = rng.integers(0 if N > 1 else 1, W + 1, size=N).astype(np.int32)
+        widths[0] = W
+        lines = [(rng.integers(0, 256, size=(H, w)).astype(dtype) if dtype == np.uint8 else rng.random((H, w), dtype=np.float32))
+                 for w in widths]
+        dst = np.full((N, H, W), 77, dtype=dtype)
+        ptrs = (C.c_void_p * N)(*[a.ctypes.data for a in lines])
+        rc = lib.cocr_collate_lines(ptrs, widths.ctypes.data_as(C.POINTER(C.c_int32)), N, H, dst.itemsize, dst.ctypes.data, W, threads)
+        assert rc == 0, lib.cocr_last_error()
+        want, lens = collate(lines, list(range(N)), W)
+        assert np.array_equal(dst, want.numpy()[:, 0].astype(dtype))
+        assert lens.tolist() == widths.tolist()
+    bad = np.array([9], dtype=np.int32)                       # wider than the batch: refused, nothing written
+    one = np.zeros((2, 9), dtype=dtype)
+    ptrs = (C.c_void_p * 1)(one.ctypes.data)
+    assert lib.cocr_collate_lines(ptrs, bad.ctypes.data_as(C.POINTER(C.c_int32)), 1, 2, one.itemsize, dst.ctypes.data, 8, 1) != 0
+    assert b'wide' in lib.cocr_last_error()
+
+
 def _hp(**kw):
     base = dict(num_classes=11, height=16, encoder_dim=32, num_encoder_layers=1, num_attention_heads=4,
                 feed_forward_expansion_factor=4, conv_expansion_factor=2, conv_kernel_size=7, half_step_residual=1,
