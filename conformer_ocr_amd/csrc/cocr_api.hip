@@ -284,6 +284,14 @@ extern "C" void cocr_destroy(cocr_model *m) {
     if (m->pre_buf) (void)hipFree(m->pre_buf);
     if (m->stamps) {
         (void)hipDeviceSynchronize();
+        if (m->stamps[1024]) {                          // row-chain kernel (dominant form), workgroup 7: per wave, cycles between stamps
+            for (int w = 0; w < 8; ++w) {
+                const unsigned long long *q = m->stamps + 1024 + 64 * w;
+                fprintf(stderr, "chain wave %d (start +%llu):", w, q[0] - m->stamps[1024]);
+                for (int i = 1; i < 64 && q[i]; ++i) fprintf(stderr, " %llu", q[i] - q[i - 1]);
+                fprintf(stderr, "  total %llu\n", [&] { int i = 1; while (i < 64 && q[i]) ++i; return q[i - 1] - q[0]; }());
+            }
+        }
         fprintf(stderr, "frontend stamps:");
         for (int i = 129; i < 192 && m->stamps[i]; ++i) fprintf(stderr, " %llu", m->stamps[i] - m->stamps[128]);
         fprintf(stderr, "\nbeam walk cycles of the stay wave, then of extension wave 0 (pairs + reads, keys, barrier + ranks, update, tail):");
@@ -1097,6 +1105,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                         a.st[3] = st_qkv(nx);
                         a.nstages = 4;
                         a.st[1].tap_pre = tp[1]; a.st[1].tap_post = tp[2]; a.st[2].tap_pre = tp[3];
+                        a.stamps = (m->stamps && l == 5) ? m->stamps + 1024 : nullptr;
                         { ProfScope ps(m, s, FAM_CH_B); GEMM_TRY(launch(a)); }
                         if (taps && ((rc = tap_common()) || (rc = tapx(l, "out", tp[2])) || (rc = tapx(l + 1, "ffn1", tp[3])) || (rc = tap_qkv(l + 1)))) return rc;
                     } else {

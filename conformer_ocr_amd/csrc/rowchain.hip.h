@@ -35,6 +35,12 @@
 #include "gemm.hip.h"
 #include "rowchain_args.hip.h"
 
+#ifndef COCR_RC_PRIO
+#define COCR_RC_PRIO 0         // dev: 1 = raised wave priority around each k-step's matrix instructions; 2 = waves 4..7 at raised priority throughout
+#endif
+#ifndef COCR_RC_HT
+#define COCR_RC_HT 0           // dev: 1 = all row tiles' operand fragments of a k-step requested at once
+#endif
 #ifndef COCR_RC_EXP
 #define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs
 #endif
@@ -52,6 +58,19 @@ __device__ __forceinline__ float butterfly4(float a, float b, float c, float d) 
     float ab = a + b, cd = c + d;          // ab: [sum over halves of a | of b]
     swap16(ab, cd);
     return ab + cd;                        // rows: a, c, b, d
+}
+
+template <int D, int MT> constexpr size_t rowchain_lds_bytes() {
+    return (size_t)(D / 64) * 16 * MT * 128 + 2 * 4 * (size_t)(16 * MT) * 128 + 4096 + 16 * (size_t)D + 12 * (size_t)(16 * MT) + 64;
+}
+// Where the depthwise taps of a channel half ((DWK + 1) rows of 256 floats) are staged in LDS: 1 = behind the window inside the hidden-image
+// area, 2 = in an area of their own behind everything else, 0 = nowhere (no room: every thread loads its own taps from global memory)
+template <int D, int MT, int DWK> constexpr int rowchain_taps_place() {
+    if (DWK == 0 || (DWK + 1) % 8 != 0) return 0;
+    constexpr size_t hsb = 2 * 4 * (size_t)(16 * MT) * 128 + 4096, win = (size_t)(16 * MT + DWK - 1) * 512, taps = (size_t)(DWK + 1) * 1024;
+    if (win + taps <= hsb) return 1;
+    if (rowchain_lds_bytes<D, MT>() + taps <= 160 * 1024) return 2;
+    return 0;
 }
 
 template <int D, int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS>
@@ -84,6 +103,14 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     const int r16 = lane & 15, g = lane >> 4, swz = r16 & 7;
     const int M = p.M, m0 = blockIdx.x * BMC, mend = min(M, m0 + BMC);
     const int lrow = lane >> 3, cpos = lane & 7;
+#ifdef COCR_CHAIN_STAMPS_BUILD
+    int sk = 0;
+#define RSTAMP() { if (p.stamps && blockIdx.x == 7 && lane == 0) p.stamps[wave * 64 + sk] = __builtin_readcyclecounter(); ++sk; }
+#else
+#define RSTAMP()
+#endif
+    RSTAMP()                                       // 0: start
+    if constexpr (COCR_RC_PRIO == 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
     auto lds_fence_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -111,19 +138,40 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     } else {
         dw_window(0);
     }
-    // depthwise taps and bias of this thread's channel pair (first channel half): requested with the window, ahead of the weight ring
-    // (loads return in order: behind the ring they would wait for all of it)
+    // depthwise taps and bias of a channel half: DWK + 1 rows of 256 floats behind the window in LDS, one DMA each, requested with the window
+    // and ahead of the weight ring (loads return in order: behind the ring they would wait for all of it).  Every thread then reads its
+    // channel pair's taps from there.  (Each thread loading its own taps from global memory -- 32 eight-byte loads, the same 32 KB four times
+    // per workgroup -- made 68 loads per wave at the kernel's start, more than the 63 a wave can have outstanding: the prologue started
+    // 16 k cycles into the launch.)
     typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
     dw_f32x2 dw_wt[DWK ? DWK : 1], dw_bias = {0.f, 0.f};
+    constexpr int TAPLACE = rowchain_taps_place<D, MT, DWK>();
+    unsigned char *tapa = TAPLACE == 1 ? hs + DWROWS * 512 : smem + rowchain_lds_bytes<D, MT>();
     auto dw_taps = [&](int h) {
-        if constexpr (DWK != 0) {
+        if constexpr (DWK != 0 && TAPLACE != 0) {
+#pragma unroll
+            for (int r = wave; r <= DWK; r += 8) {           // (DWK + 1) % 8 == 0: the same number of requests in every wave
+                const float *src = (r < DWK ? p.dw_w + (size_t)r * D : p.dw_b) + h * 256 + lane * 4;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(tapa + r * 1024), 16, 0, 0);
+            }
+        } else if constexpr (DWK != 0) {
             const int c = h * 256 + 2 * (tid & 127);
 #pragma unroll
             for (int tau = 0; tau < DWK; ++tau) dw_wt[tau] = *reinterpret_cast<const dw_f32x2 *>(p.dw_w + (size_t)tau * D + c);
             dw_bias = *reinterpret_cast<const dw_f32x2 *>(p.dw_b + c);
         }
     };
+    auto dw_taps_read = [&]() {                    // after the barrier that publishes the window and the taps
+        if constexpr (DWK != 0 && TAPLACE != 0) {
+            const unsigned char *tb = tapa + (tid & 127) * 8;
+#pragma unroll
+            for (int tau = 0; tau < DWK; ++tau) dw_wt[tau] = *reinterpret_cast<const dw_f32x2 *>(tb + tau * 1024);
+            dw_bias = *reinterpret_cast<const dw_f32x2 *>(tb + DWK * 1024);
+        }
+    };
+    RSTAMP()                                       // window / operand tile requested
     dw_taps(0);
+    RSTAMP()                                       // taps requested
     // ---- weight ring: the first step's 16 fragments
     bf16x8 ring[16];
     auto fill = [&](const T *slice, int f) { ring[f] = *reinterpret_cast<const bf16x8 *>(slice + f * 512 + lane * 8); };
@@ -133,27 +181,36 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
         for (int f = 0; f < 16; ++f) fill(first, f);
     }
     __builtin_amdgcn_sched_barrier(0);
+    RSTAMP()                                       // ring requested
     // ---- the residual stream of this workgroup's rows, in the accumulator layout: xs[i][2 ns + j][q] = x[m0 + 16 i + r16][256 ns + 32 wave + 16 j + 4 g + q].
     // Requested AFTER the operand tile / depthwise window and the ring (loads return in order): the prologue and the first product do not
     // wait for these 16 MT D bytes per wave (a CU takes in ~10 B per cycle: 96 KiB = 4.6 us), only the first epilogue does.
+    // With the depthwise prologue they are requested after it: their 8 MT NJ registers are free for the prologue (with them the ring did
+    // not fit: fragments were parked in scratch memory at the kernel's start, i.e. waited for), and the first product hides them.
     f32x4 xs[MT][NJ];
+    auto load_stream = [&]() {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const float *xrow = p.x + (size_t)min(m0 + 16 * i + r16, mend - 1) * D + 32 * wave + 4 * g;
+        for (int i = 0; i < MT; ++i) {
+            const float *xrow = p.x + (size_t)min(m0 + 16 * i + r16, mend - 1) * D + 32 * wave + 4 * g;
 #pragma unroll
-        for (int c = 0; c < NJ; ++c) {
-            if constexpr (COCR_RC_EXP & 1) xs[i][c] = (f32x4){(float)r16, 1.f, (float)g, 0.5f};
-            else xs[i][c] = *reinterpret_cast<const f32x4 *>(xrow + 256 * (c >> 1) + 16 * (c & 1));
+            for (int c = 0; c < NJ; ++c) {
+                if constexpr (COCR_RC_EXP & 1) xs[i][c] = (f32x4){(float)r16, 1.f, (float)g, 0.5f};
+                else xs[i][c] = *reinterpret_cast<const f32x4 *>(xrow + 256 * (c >> 1) + 16 * (c & 1));
+            }
         }
-    }
+    };
+    constexpr int EARLY_XS = DWK == 0 ? MT * NJ : 0;     // stream loads in flight at the first wait
+    if constexpr (DWK == 0) load_stream();
     __builtin_amdgcn_sched_barrier(0);
     if (tid < BMC) {
         const int m = min(m0 + tid, M - 1), b = m / p.T_, t = m - b * p.T_;
         rowoff[tid] = ((long long)b * p.heads * p.Tp + t) * p.dhp;
         tpos[tid] = t;
     }
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 + MT * NJ) : "memory");        // the operand DMAs (older than the ring and stream loads) have landed
+    RSTAMP()                                       // 1: loads requested
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 + EARLY_XS) : "memory");       // the operand DMAs (older than the ring and stream loads) have landed
     lds_fence_barrier();
+    RSTAMP()                                       // 2: operand tile / window landed
 
     if constexpr (DWK != 0) {
         // Depthwise conv (kernel DWK, zero padding at the line ends, BatchNorm folded) + SiLU on the GLU output (convolution.py:140-142),
@@ -172,6 +229,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                 lds_fence_barrier();
             }
             const int c = 2 * cp;                            // channel inside the half
+            dw_taps_read();
             const f32x2_t bias = dw_bias;
             // rows of this thread: quarter rq of the block, in groups of 8 (a ragged last group re-does rows of the previous one)
             constexpr int RQ = BMC / 4;
@@ -219,6 +277,9 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             }
             lds_fence_barrier();                             // this half of the operand image complete; the window is free
         }
+        load_stream();
+        __builtin_amdgcn_sched_barrier(0);
+        RSTAMP()                                   // 3: depthwise prologue done
     }
 
     // One step: acc[rows][32 columns of this wave] += image[256 k] . ring ; ring <- the 16 fragments at `nxt`.  `side(kk)` is independent VALU
@@ -229,17 +290,19 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             // row tiles in two halves: half the operand registers live
-            constexpr int HT = MT > 3 ? MT / 2 : MT;
+            constexpr int HT = COCR_RC_HT ? MT : (MT > 3 ? MT / 2 : MT);
 #pragma unroll
             for (int h0 = 0; h0 < MT; h0 += HT) {
                 bf16x8 a[HT];
 #pragma unroll
                 for (int i = 0; i < HT; ++i) a[i] = lds_frag_swz(img + (kk >> 1) * PANEL + (16 * (h0 + i) + r16) * 128, kk & 1, g, swz, T());
+                if constexpr (COCR_RC_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int i = 0; i < HT; ++i)
                         acc[h0 + i][c0 + j] = mma16(ring[2 * kk + j], a[i], (fresh && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[h0 + i][c0 + j]);
+                if constexpr (COCR_RC_PRIO == 1) __builtin_amdgcn_s_setprio(0);
             }
             fill(nxt, 2 * kk);
             fill(nxt, 2 * kk + 1);
@@ -387,9 +450,9 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             // x_new = x + bias + A W^T: NS column steps x KS k-slices
             request_ln_params(st);
             auto slice = [&](int ns, int ks) { return st.W + ((size_t)(ns * 8 + wave) * KS + ks) * SLICE; };
-            if constexpr (decltype(FIRST)::value && DWK == 0) {
-                // first stage of a launch without a prologue: the stream is still on its way -- the product starts from zero and the
-                // stream (+ bias) is added afterwards
+            if constexpr (decltype(FIRST)::value) {
+                // first stage of a launch: the stream is still on its way -- the product starts from zero and the stream (+ bias) is
+                // added afterwards
                 f32x4 acc[MT][NJ];
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)
@@ -413,7 +476,9 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                     for (int ks = 0; ks < KS; ++ks)
                         step(xa + ks * 4 * PANEL, xs, 2 * ns, ks + 1 < KS ? slice(ns, ks + 1) : (ns + 1 < NS ? slice(ns + 1, 0) : after), no_side, std::false_type{});
             }
+            RSTAMP()                               // product done
             rowln_epilogue(st, hs);
+            RSTAMP()                               // epilogue done
         } else if constexpr (kind == ST_FFN) {
             // Software pipeline over the 256-wide hidden chunks:   P1(c): hidden(c) = xa W1(c)^T                  (KS steps)
             //                                                      P2(c-1): stream += silu(hidden(c-1)) W2(c-1)^T  (NS steps)  beside
@@ -424,8 +489,12 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             auto w2 = [&](int c, int ns) { return st.W2 + ((size_t)(ns * 8 + wave) * (FF / 32) + c * 8) * 1024; };
             f32x4 acc1[MT][2];
             Bias2 bb;
-            auto silu_tile = [&](int tIdx, unsigned char *hb) {          // tile t = (row tile t / 2, column tile t % 2) of acc1 -> hb
+            auto silu_tile = [&](int tIdx, unsigned char *hb, auto PIN) {  // tile t = (row tile t / 2, column tile t % 2) of acc1 -> hb
                 const int i = tIdx >> 1, j = tIdx & 1;
+                // PIN: called from a k-step -- the arithmetic below is pure, and instruction selection otherwise gathers all twelve tiles'
+                // worth of it in one block ahead of the product's first k-step (seen in the ISA: only the LDS stores stayed inside the
+                // steps), where nothing overlaps it; an empty volatile asm on the inputs keeps each tile between its step's fences
+                if constexpr (decltype(PIN)::value) asm volatile("" : "+v"(acc1[i][j]));
                 const int jj = 32 * wave + 16 * j + 4 * g;               // hidden column inside the chunk
                 const int ch16 = (jj & 63) >> 3, row = 16 * i + r16;
                 // packed fp32 arithmetic around the two transcendentals: 5 packed + 4 transcendental + 1 convert per value pair
@@ -453,28 +522,36 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             request_ln_params(st);
             bb = load_bias(st.bias);
             p1(0, nchunks > 1 ? w1(1, 0) : w2(0, 0));                     // P1(0)
+            RSTAMP()                                                      // P1(0) done
 #pragma unroll
-            for (int t2 = 0; t2 < 2 * MT; ++t2) silu_tile(t2, hs);       // S(0)
+            for (int t2 = 0; t2 < 2 * MT; ++t2) silu_tile(t2, hs, std::false_type{});       // S(0)
             add_bias_to_stream(st.bias2, st.alpha);                       // stream + alpha b2 = the second product's initial accumulator (after P1(0):
                                                                           // as a launch's first stage the stream loads are still in flight before)
+            RSTAMP()                                                      // S(0) done
             lds_fence_barrier();
+            RSTAMP()                                                      // barrier
             for (int c = 1; c < nchunks; ++c) {
                 bb = load_bias(st.bias + c * 256);
                 p1(c, w2(c - 1, 0));                                      // P1(c)
+                RSTAMP()                                                  // P1(c) done
                 unsigned char *hb = hs + (c & 1) * IMGH;
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)                           // P2(c-1) beside S(c): the 2 MT tiles spread over the NS x 8 k-steps
                     step(hs + ((c - 1) & 1) * IMGH, xs, 2 * ns, ns + 1 < NS ? w2(c - 1, ns + 1) : (c + 1 < nchunks ? w1(c + 1, 0) : w2(c, 0)),
                          [&](int kk) {
 #pragma unroll
-                             for (int t2 = 0; t2 < 2 * MT; ++t2) if ((t2 * 8 * NS) / (2 * MT) == ns * 8 + kk) silu_tile(t2, hb);
+                             for (int t2 = 0; t2 < 2 * MT; ++t2) if ((t2 * 8 * NS) / (2 * MT) == ns * 8 + kk) silu_tile(t2, hb, std::true_type{});
                          }, std::false_type{});
+                RSTAMP()                                                  // P2(c-1) + S(c) done
                 lds_fence_barrier();
+                RSTAMP()                                                  // barrier
             }
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns)                               // P2(last)
                 step(hs + ((nchunks - 1) & 1) * IMGH, xs, 2 * ns, ns + 1 < NS ? w2(nchunks - 1, ns + 1) : after, no_side, std::false_type{});
+            RSTAMP()                                                      // P2(last) done
             rowln_epilogue(st, hs + (nchunks & 1) * IMGH);               // partials in the hidden image the last product did not read
+            RSTAMP()                                                      // epilogue done
         } else if constexpr (kind == ST_GLU) {
             // 2 D packed columns in steps of 256: wave w's pair = (value tile, gate tile) of channels 128 step + 16 w .. +15
             EpiGLU<T> e{st.out, D, st.bias, 2 * D};
@@ -528,6 +605,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                         for (int q = 0; q < 4; ++q) o[q] = (T)(acc[i][j][q] + bb.v[j][q]);
                         *reinterpret_cast<bf16x4 *>(tile + row * OS + (32 * wave + 16 * j + 4 * g) * 2) = o;
                     }
+                RSTAMP()                                     // product + staging of step s3 done
                 lds_fence_barrier();                         // tile s3 complete (tile s3-1 was flushed before this barrier)
                 {   // thread -> one 8-column chunk of BMC / 16 rows
                     const int which = s3 / NS;
@@ -548,15 +626,13 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     run_stage(std::integral_constant<int, K1>{}, std::false_type{}, p.st[1], K2 >= 0 ? first_slice(2) : first_slice(0));
     run_stage(std::integral_constant<int, K2>{}, std::false_type{}, p.st[2], K3 >= 0 ? first_slice(3) : first_slice(0));
     run_stage(std::integral_constant<int, K3>{}, std::false_type{}, p.st[3], first_slice(0));
-}
-
-template <int D, int MT> constexpr size_t rowchain_lds_bytes() {
-    return (size_t)(D / 64) * 16 * MT * 128 + 2 * 4 * (size_t)(16 * MT) * 128 + 4096 + 16 * (size_t)D + 12 * (size_t)(16 * MT) + 64;
+    RSTAMP()                                       // end
+#undef RSTAMP
 }
 
 template <int D, int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS>
 static inline hipError_t launch_rowchain_mt(hipStream_t s, const ChainArgs &a) {
-    constexpr size_t lds = rowchain_lds_bytes<D, MT>();
+    constexpr size_t lds = rowchain_lds_bytes<D, MT>() + (rowchain_taps_place<D, MT, DWK>() == 2 ? (size_t)(DWK + 1) * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
     auto kern = rowchain_kernel<D, MT, DWK, K0, K1, K2, K3, TAPS>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);

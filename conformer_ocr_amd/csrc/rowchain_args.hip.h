@@ -33,6 +33,7 @@ struct ChainArgs {
     bf16_t *tap_dw;        // debug tap (TAPS instantiation): (M, D) copy of the prologue's output, or null
     int dh, dhp, heads, T_, Tp;       // attention layout of the QKV stage
     float inv_d;           // 1 / (LayerNorm width): 1 / D, or 1 / (the model's own encoder_dim) when D is a zero-padded width (cocr_api: set_engine_dims)
+    unsigned long long *stamps;    // dev builds (COCR_CHAIN_STAMPS_BUILD): host-visible cycle stamps [wave][64] of workgroup 7, or null
     ChainStage st[4];
 };
 

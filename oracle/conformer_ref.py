@@ -241,9 +241,10 @@ class Oracle:
             taps[f'l{l}.ctx'] = ctx
         return y + out
 
-    def convmod(self, y: torch.Tensor, l: int, taps: Optional[dict] = None) -> torch.Tensor:
+    def convmod(self, y: torch.Tensor, l: int, taps: Optional[dict] = None, glu: Optional[torch.Tensor] = None) -> torch.Tensor:
         """convolution.py:135-148 (SURVEY A.1b CONV): LN -> PW(D->2D) -> GLU -> depthwise k (zero pad at the
-        PADDED batch edges) -> BatchNorm(eval, folded) -> SiLU -> PW(D->D); residual x1 (modules.py:32)."""
+        PADDED batch edges) -> BatchNorm(eval, folded) -> SiLU -> PW(D->D); residual x1 (modules.py:32).
+        `glu`: continue from this GLU output instead of the one computed here (tests that check the depthwise stage in isolation)."""
         hp = self.hp
         B, T, D = y.shape
         k = hp.conv_kernel_size
@@ -251,6 +252,8 @@ class Oracle:
         t = self._ln_op(y, c + '0')
         a = t @ self.w[c + '2.conv.weight'].squeeze(-1).t() + self.w[c + '2.conv.bias']   # (B,T,2D)
         g = self.r(a[..., :D] * torch.sigmoid(a[..., D:]))
+        if glu is not None:
+            g = glu
         gp = F.pad(g, (0, 0, (k - 1) // 2, (k - 1) // 2))                      # zero rows before/after time
         if self.training:
             # nn.BatchNorm1d in train mode (convolution.py:141): statistics over ALL (batch, frame) positions of the padded batch

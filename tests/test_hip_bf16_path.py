@@ -102,9 +102,11 @@ def test_chain_kernel_stages_in_isolation_against_bf16_oracle(n, w):
             stream(f'l{l}.mhsa', tap(f'l{l}.mhsa'), ref)
             y = tap(f'l{l}.mhsa')
             t = {}
-            ref = o.convmod(y, l, t)
+            o.convmod(y, l, t)
             stored(f'l{l}.glu', tap(f'l{l}.glu'), t[f'l{l}.glu'])
-            stored(f'l{l}.dw', tap(f'l{l}.dw'), t[f'l{l}.dw'])
+            t = {}
+            ref = o.convmod(y, l, t, glu=tap(f'l{l}.glu'))             # the depthwise stage from the HIP path's own GLU output: one flipped
+            stored(f'l{l}.dw', tap(f'l{l}.dw'), t[f'l{l}.dw'])          # bf16 rounding of a large GLU value times a tap is not this stage's error
             stream(f'l{l}.conv', tap(f'l{l}.conv'), ref)
             y = tap(f'l{l}.conv')
             stream(f'l{l}.ffn2', tap(f'l{l}.ffn2'), o.ffn(y, l, 3))
@@ -227,7 +229,10 @@ def test_fast_path_against_per_product_kernels(text_case, flag, monkeypatch):
     d = float(np.abs(a - b).max())
     la, lb = a.argmax(-1), b.argmax(-1)
     _log(f'ab_{flag}', {'max_abs_logit_diff': d, 'label_diff_frames': int((la != lb).sum())})
-    assert d > 0.0                       # the flag did select other kernels
+    if flag == 'COCR_NO_DW_FUSE':        # the stand-alone depthwise kernel accumulates in the prologue's order and the first product now starts
+        assert d == 0.0, d               # from zero in both forms: bit-identical (that the flag selects another kernel shows in the profile)
+    else:
+        assert d > 0.0                   # the flag did select other kernels
     assert d <= 0.35, d                  # logits of +-30 after 12 blocks; other accumulation orders flip borderline bf16 roundings
     assert int((la != lb).sum()) == 0
     assert all(_greedy(la[n]) == _greedy(lb[n]) == tc.ref_strings[idx[n]] for n in range(len(idx)))
