@@ -35,12 +35,6 @@
 #include "gemm.hip.h"
 #include "rowchain_args.hip.h"
 
-#ifndef COCR_RC_PRIO
-#define COCR_RC_PRIO 0         // dev: 1 = raised wave priority around each k-step's matrix instructions; 2 = waves 4..7 at raised priority throughout
-#endif
-#ifndef COCR_RC_HT
-#define COCR_RC_HT 0           // dev: 1 = all row tiles' operand fragments of a k-step requested at once
-#endif
 #ifndef COCR_RC_EXP
 #define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs
 #endif
@@ -110,7 +104,6 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #define RSTAMP()
 #endif
     RSTAMP()                                       // 0: start
-    if constexpr (COCR_RC_PRIO == 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
     auto lds_fence_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -290,19 +283,17 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             // row tiles in two halves: half the operand registers live
-            constexpr int HT = COCR_RC_HT ? MT : (MT > 3 ? MT / 2 : MT);
+            constexpr int HT = MT > 3 ? MT / 2 : MT;
 #pragma unroll
             for (int h0 = 0; h0 < MT; h0 += HT) {
                 bf16x8 a[HT];
 #pragma unroll
                 for (int i = 0; i < HT; ++i) a[i] = lds_frag_swz(img + (kk >> 1) * PANEL + (16 * (h0 + i) + r16) * 128, kk & 1, g, swz, T());
-                if constexpr (COCR_RC_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int i = 0; i < HT; ++i)
                         acc[h0 + i][c0 + j] = mma16(ring[2 * kk + j], a[i], (fresh && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[h0 + i][c0 + j]);
-                if constexpr (COCR_RC_PRIO == 1) __builtin_amdgcn_s_setprio(0);
             }
             fill(nxt, 2 * kk);
             fill(nxt, 2 * kk + 1);
