@@ -148,47 +148,53 @@ def collate(lines: Sequence[np.ndarray], idx: Sequence[int], width: int) -> Tupl
 
 
 class _PinnedPool:
-    """Pinned (N,1,H,W) staging tensors, kept across calls: pinning host memory costs milliseconds per allocation (a fresh
-    `pin_memory()` per batch held the whole loop at ~2 k lines/s), so a shape's buffers are allocated once, handed out through a queue
-    and handed back together with the event of the copy that read them.  Least recently used shapes are dropped beyond `cap` bytes."""
+    """Pinned staging memory, kept across calls: pinning host memory costs milliseconds per allocation (a fresh `pin_memory()` per
+    batch held the whole loop at ~2 k lines/s; a set of buffers per batch SHAPE still made the first pass over a mixed-width queue
+    -- eleven bucket widths, full and partial batches -- allocate for half a second).  Buffers are flat byte runs in power-of-two
+    size classes (at least 1 MiB); a batch of any shape is a view of the first bytes of one.  A class's buffers are allocated
+    on demand up to `depth`, handed out through a queue and handed back together with the event of the copy that read them.
+    Least recently used classes are dropped beyond `cap` bytes."""
 
     def __init__(self, cap: int = 2 << 30):
         import queue
         import threading
         self._queue = queue.Queue
         self.lock = threading.Lock()
-        self.shapes: Dict[tuple, list] = {}         # key -> [free queue, buffers allocated, bytes per buffer]
+        self.classes: Dict[int, list] = {}          # bytes per buffer -> [free queue, buffers allocated]
         self.cap = cap
 
-    def take(self, key: tuple, depth: int) -> torch.Tensor:
+    @staticmethod
+    def size_class(nbytes: int) -> int:
+        return max(1 << 20, 1 << (max(nbytes, 1) - 1).bit_length())
+
+    def take(self, shape: tuple, dtype: torch.dtype, depth: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(flat pinned buffer, its first bytes viewed as `shape` of `dtype`)."""
+        nbytes = int(np.prod(shape)) * (1 if dtype == torch.uint8 else 4)
+        key = self.size_class(nbytes)
         with self.lock:
-            ent = self.shapes.pop(key, None)
-            if ent is None:
-                n, h, w, dtype = key
-                ent = [self._queue(), 0, n * h * w * (1 if dtype == torch.uint8 else 4)]
-            self.shapes[key] = ent                   # most recently used last
+            ent = self.classes.pop(key, None) or [self._queue(), 0]
+            self.classes[key] = ent                  # most recently used last
             grow = ent[0].empty() and ent[1] < depth
             if grow:
                 ent[1] += 1
-                total = sum(e[1] * e[2] for e in self.shapes.values())
-                for k in list(self.shapes):
+                total = sum(e[1] * k for k, e in self.classes.items())
+                for k in list(self.classes):
                     if total <= self.cap or k == key:
                         break
-                    e = self.shapes.pop(k)           # its tensors are freed once their last holders let go
-                    total -= e[1] * e[2]
+                    total -= self.classes.pop(k)[1] * k      # its tensors are freed once their last holders let go
         if grow:
-            n, h, w, dtype = key
-            return torch.empty((n, 1, h, w), dtype=dtype).pin_memory()
-        buf, copied = ent[0].get()
-        if copied is not None:
-            copied.synchronize()
-        return buf
+            flat = torch.empty(key, dtype=torch.uint8).pin_memory()
+        else:
+            flat, copied = ent[0].get()
+            if copied is not None:
+                copied.synchronize()
+        return flat, flat[:nbytes].view(dtype).view(shape)
 
-    def give(self, key: tuple, buf: torch.Tensor, copied) -> None:
+    def give(self, flat: torch.Tensor, copied) -> None:
         with self.lock:
-            ent = self.shapes.get(key)
+            ent = self.classes.get(flat.numel())
         if ent is not None:
-            ent[0].put((buf, copied))
+            ent[0].put((flat, copied))
 
 
 _PINNED = _PinnedPool()
@@ -201,7 +207,7 @@ class _Stager:
     float32.  Iterating yields (line indices, pinned batch, widths, key); the consumer calls `release(key, batch, copy event)`."""
 
     def __init__(self, lines: Sequence[np.ndarray], batches: Sequence[Tuple[int, List[int]]], order: Iterable[int], depth: int,
-                 threads: int = 4, ahead: int = 2):
+                 threads: int = 8, ahead: int = 2):
         import queue
         import threading
         from . import _lib
@@ -224,8 +230,7 @@ class _Stager:
         for a in src:
             if a.ndim != 2 or a.shape[0] != h or a.shape[1] > width:
                 raise ValueError(f'line of shape {a.shape} in a batch of height {h}, width {width}')
-        key = (len(idx), h, width, dtype)
-        buf = _PINNED.take(key, self.depth)
+        key, buf = _PINNED.take((len(idx), 1, h, width), dtype, self.depth)      # key: the flat buffer to hand back
         widths = np.array([a.shape[1] for a in src], dtype=np.int32)
         ptrs = (C.c_void_p * len(src))(*[a.__array_interface__['data'][0] for a in src])
         rc = self.lib.cocr_collate_lines(ptrs, widths.ctypes.data_as(C.POINTER(C.c_int32)), len(src), h, 1 if u8 else 4,
@@ -255,8 +260,8 @@ class _Stager:
             yield item
 
     @staticmethod
-    def release(key: tuple, buf: torch.Tensor, copied) -> None:
-        _PINNED.give(key, buf, copied)
+    def release(key: torch.Tensor, buf: torch.Tensor, copied) -> None:
+        _PINNED.give(key, copied)
 
     def close(self) -> None:
         self.stop = True
@@ -264,7 +269,7 @@ class _Stager:
             try:
                 item = self.ready.get(timeout=0.05)
                 if isinstance(item, tuple):
-                    _PINNED.give(item[3], item[1], None)
+                    _PINNED.give(item[3], None)
             except Exception:
                 pass
         self.thread.join()
