@@ -182,12 +182,17 @@ class _PinnedPool:
                     if total <= self.cap or k == key:
                         break
                     total -= self.classes.pop(k)[1] * k      # its tensors are freed once their last holders let go
+        if not grow:
+            try:
+                flat, copied = ent[0].get(timeout=2.0)
+                if copied is not None:
+                    copied.synchronize()
+            except Exception:                        # queue.Empty: a consumer that failed kept its buffers -- allocate rather than wait for ever
+                with self.lock:
+                    ent[1] += 1
+                grow = True
         if grow:
             flat = torch.empty(key, dtype=torch.uint8).pin_memory()
-        else:
-            flat, copied = ent[0].get()
-            if copied is not None:
-                copied.synchronize()
         return flat, flat[:nbytes].view(dtype).view(shape)
 
     def give(self, flat: torch.Tensor, copied) -> None:

@@ -108,3 +108,23 @@ def test_validation_step_loss_and_metrics(case):
     truths[5] = truths[5] + 'xy'
     rep2 = validate(net, lines, truths, batch_size=4)
     assert abs(rep2['cer'] - 3 / rep2['chars']) < 1e-12 and rep2['val_loss'] != rep['val_loss']
+
+
+def test_pinned_staging_pool_shares_buffers_between_batch_shapes():
+    """The loop's pinned staging memory: one size class serves every batch shape that fits it, a buffer comes back with the event of
+    the copy that read it, and a consumer that never gives its buffers back does not stall the next taker for ever."""
+    from conformer_ocr_amd.evaluate import _PinnedPool
+    pool = _PinnedPool()
+    flat_a, a = pool.take((3, 1, 16, 100), torch.float32, depth=2)
+    assert a.shape == (3, 1, 16, 100) and a.dtype == torch.float32 and a.is_pinned() and flat_a.numel() == 1 << 20
+    a.fill_(0.5)
+    dev = a.to('cuda:0', non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    pool.give(flat_a, ev)
+    flat_b, b = pool.take((2, 1, 16, 50), torch.uint8, depth=1)            # another shape and type, the same 1 MiB class: the same memory
+    assert flat_b.data_ptr() == flat_a.data_ptr() and b.shape == (2, 1, 16, 50) and b.dtype == torch.uint8
+    assert float(dev.min()) == 0.5                                           # (the copy had finished before the buffer was handed out again)
+    flat_c, _ = pool.take((2, 1, 16, 50), torch.uint8, depth=1)            # flat_b was never given back: a fresh buffer after the wait
+    assert flat_c.data_ptr() != flat_b.data_ptr()
+    assert _PinnedPool.size_class(3 << 20) == 4 << 20 and _PinnedPool.size_class(1) == 1 << 20
