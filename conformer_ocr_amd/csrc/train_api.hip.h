@@ -46,6 +46,8 @@ extern "C" int cocr_train_set_matmul(cocr_model *m, int bf16_operands) {
 
 extern "C" int cocr_train_begin(cocr_model *m) {
     if (!m) return fail(COCR_EINVAL, "null argument");
+    if (m->hp.subsampling_conv_channels % 4 != 0 || m->hp.subsampling_conv_channels > 1024)
+        return fail(COCR_EUNSUPPORTED, "training: subsampling_conv_channels must be a multiple of 4 and at most 1024 (is %d)", m->hp.subsampling_conv_channels);
     HIP_TRY(hipSetDevice(m->device));
     train_free(m);
     TrainState *t = new TrainState();
@@ -197,7 +199,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     }
     const size_t oZg = rsv((size_t)M * C * F), oZa = rsv(big_rows * C), oZb = rsv(big_rows * C), oZ1g = rsv((size_t)N * Ts[0] * Fs[0] * C);
     const size_t part_floats = std::max((size_t)ceil_div((int)std::min<size_t>(big_rows, 1u << 30), COCR_CS_ROWS) * (size_t)std::max(wide, C * 10),
-                                        (size_t)ceil_div((int)std::min<size_t>((size_t)N * Ts[0] * Fs[0], 1u << 30), COCR_CV_POS) * 10 * (size_t)C);
+                                        (size_t)ceil_div(N * Ts[0], COCR_CV_ROWS) * 10 * (size_t)C);
     const size_t oPart = rsv(part_floats + 4096), oVec = rsv(4 * (size_t)std::max(D, C) + 64);
     // weight gradients are tall-K products (K = rows): split-K partial sums [splits][out x in]
     auto wg_splits = [](int Nc, int Kr) { const int tiles = ceil_div(Nc, COCR_FO_BM) * ceil_div(Kr, COCR_FO_BN); return std::max(1, std::min(32, 512 / tiles)); };
@@ -333,20 +335,26 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     float *X = WS(oX);
     if (line_dtype == COCR_U8) hipLaunchKernelGGL(k_u8_to_f32, grid1((size_t)N * H * W), dim3(256), 0, s, (const uint8_t *)lines, X, (size_t)N * H * W);
     else copy(X, (const float *)lines, (size_t)N * H * W);
-    hipLaunchKernelGGL(k_conv0_fwd, grid1((size_t)N * Ts[0] * Fs[0] * C), dim3(256), 0, s, X, Pp("encoder.conv_subsample.conv.0.weight"),
+    hipLaunchKernelGGL(k_conv0_fwd, dim3(N * Ts[0]), dim3(256), 0, s, X, Pp("encoder.conv_subsample.conv.0.weight"),
                        Pp("encoder.conv_subsample.conv.0.bias"), WS(oZ1), N, H, W, Ts[0], Fs[0], C);
+    const size_t cw_lds = (size_t)(256 / (C / 4)) * 10 * C * sizeof(float);          // conv_w_block_sum: [position phases][10][C]
+    auto tfc = [&](const float *in, float *out, int reverse) {                       // (n, t, f, c) <-> (n, t, c, f), a row per block through LDS
+        const size_t lds = (size_t)F * (C + 1) * sizeof(float);
+        if (lds <= 64 * 1024) hipLaunchKernelGGL(k_tfc_to_tcf, dim3(M), dim3(256), lds, s, in, out, (size_t)M, F, C, reverse);
+        else hipLaunchKernelGGL(k_tfc_to_tcf_flat, grid1((size_t)M * F * C), dim3(256), 0, s, in, out, (size_t)M, F, C, reverse);
+    };
     auto conv_name = [&](int idx, const char *leaf) { snprintf(nb, sizeof nb, "encoder.conv_subsample.conv.%d.%s", idx, leaf); return std::string(nb); };
     {
         const float *zin = WS(oZ1);
         for (int i = 0, idx = 2; i + 1 < snum; ++i, idx += 3) {
             const size_t rows = (size_t)N * Ts[i + 1] * Fs[i + 1];
-            hipLaunchKernelGGL(k_dw3_fwd, grid1(rows * C), dim3(256), 0, s, zin, Pp(conv_name(idx, "weight")), Pp(conv_name(idx, "bias")), WS(stg[i].z2),
+            hipLaunchKernelGGL(k_dw3_fwd, dim3(N * Ts[i + 1]), dim3(256), 0, s, zin, Pp(conv_name(idx, "weight")), Pp(conv_name(idx, "bias")), WS(stg[i].z2),
                                N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
             if ((rc = lin_fwd(WS(stg[i].z2), conv_name(idx + 1, "weight"), conv_name(idx + 1, "bias"), (int)rows, C, C, WS(stg[i].z3)))) return rc;
             hipLaunchKernelGGL(k_relu, grid1(rows * C), dim3(256), 0, s, WS(stg[i].z3), rows * C);
             zin = WS(stg[i].z3);
         }
-        hipLaunchKernelGGL(k_tfc_to_tcf, grid1((size_t)M * F * C), dim3(256), 0, s, zin, WS(oZt), (size_t)M, F, C, 0);
+        tfc(zin, WS(oZt), 0);
     }
     if ((rc = lin_fwd(WS(oZt), "encoder.conv_subsample.out.0.weight", "encoder.conv_subsample.out.0.bias", M, D, C * F, WS(lay[0].x_in)))) return rc;
     dropout(WS(lay[0].x_in), MD, p_in, 1);
@@ -538,23 +546,23 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     if ((rc = lin_bwd(dx, WS(oZt), "encoder.conv_subsample.out.0.weight", "encoder.conv_subsample.out.0.bias", M, D, C * F, WS(oZg)))) return rc;
     {
         float *dz3 = snum == 1 ? WS(oZ1g) : WS(oZa), *dz2 = WS(oZb);      // (factor 2: the flattened tensor IS conv.0's output)
-        hipLaunchKernelGGL(k_tfc_to_tcf, grid1((size_t)M * F * C), dim3(256), 0, s, WS(oZg), dz3, (size_t)M, F, C, 1);
+        tfc(WS(oZg), dz3, 1);
         for (int i = snum - 2, idx = 2 + 3 * (snum - 2); i >= 0; --i, idx -= 3) {
             const size_t rows = (size_t)N * Ts[i + 1] * Fs[i + 1];
-            hipLaunchKernelGGL(k_relu_bwd, grid1(rows * C), dim3(256), 0, s, WS(stg[i].z3), dz3, rows * C);
+            if (i == snum - 2) hipLaunchKernelGGL(k_relu_bwd, grid1(rows * C), dim3(256), 0, s, WS(stg[i].z3), dz3, rows * C);     // (later stages: masked where it was produced)
             if ((rc = lin_bwd(dz3, WS(stg[i].z2), conv_name(idx + 1, "weight"), conv_name(idx + 1, "bias"), (int)rows, C, C, dz2))) return rc;
             const float *zin = i == 0 ? WS(oZ1) : WS(stg[i - 1].z3);
-            const int chunks = ceil_div((int)rows, COCR_CV_POS);
-            hipLaunchKernelGGL(k_dw3_bwd_w, dim3(ceil_div(C, 64), chunks), dim3(64), 0, s, dz2, zin, WS(oPart), N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
-            hipLaunchKernelGGL(k_conv_w_final, dim3(ceil_div(C * 10, 256)), dim3(256), 0, s, WS(oPart), chunks, C, Gp(conv_name(idx, "weight")), Gp(conv_name(idx, "bias")));
+            const int chunks = ceil_div(N * Ts[i + 1], COCR_CV_ROWS);
+            hipLaunchKernelGGL(k_dw3_bwd_w, dim3(chunks), dim3(256), cw_lds, s, dz2, zin, WS(oPart), N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
+            hipLaunchKernelGGL(k_conv_w_final, dim3(ceil_div(C * 10, 64)), dim3(256), 0, s, WS(oPart), chunks, C, Gp(conv_name(idx, "weight")), Gp(conv_name(idx, "bias")));
+            // d (stage input), masked by the ReLU that produced that input (conv.0's for i == 0, the previous stage's conv.3's otherwise)
             float *dzin = i == 0 ? WS(oZ1g) : dz3;              // (for i > 0 the previous stage's d z3 has the shape of z3[i-1] <= big_rows x C)
-            hipLaunchKernelGGL(k_dw3_bwd_in, grid1((size_t)N * Ts[i] * Fs[i] * C), dim3(256), 0, s, dz2, Pp(conv_name(idx, "weight")), dzin, N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
+            hipLaunchKernelGGL(k_dw3_bwd_in, dim3(N * Ts[i]), dim3(256), 0, s, dz2, Pp(conv_name(idx, "weight")), dzin, zin, N, Ts[i], Fs[i], Ts[i + 1], Fs[i + 1], C);
         }
-        const size_t n1 = (size_t)N * Ts[0] * Fs[0];
-        hipLaunchKernelGGL(k_relu_bwd, grid1(n1 * C), dim3(256), 0, s, WS(oZ1), WS(oZ1g), n1 * C);
-        const int chunks = ceil_div((int)n1, COCR_CV_POS);
-        hipLaunchKernelGGL(k_conv0_bwd_w, dim3(ceil_div(C, 64), chunks), dim3(64), 0, s, WS(oZ1g), X, WS(oPart), N, H, W, Ts[0], Fs[0], C);
-        hipLaunchKernelGGL(k_conv_w_final, dim3(ceil_div(C * 10, 256)), dim3(256), 0, s, WS(oPart), chunks, C, Gp("encoder.conv_subsample.conv.0.weight"),
+        if (snum == 1) hipLaunchKernelGGL(k_relu_bwd, grid1((size_t)N * Ts[0] * Fs[0] * C), dim3(256), 0, s, WS(oZ1), WS(oZ1g), (size_t)N * Ts[0] * Fs[0] * C);
+        const int chunks = ceil_div(N * Ts[0], COCR_CV_ROWS);
+        hipLaunchKernelGGL(k_conv0_bwd_w, dim3(chunks), dim3(256), cw_lds, s, WS(oZ1g), X, WS(oPart), N, H, W, Ts[0], Fs[0], C);
+        hipLaunchKernelGGL(k_conv_w_final, dim3(ceil_div(C * 10, 64)), dim3(256), 0, s, WS(oPart), chunks, C, Gp("encoder.conv_subsample.conv.0.weight"),
                            Gp("encoder.conv_subsample.conv.0.bias"));
     }
     LAUNCH_CHECK();

@@ -470,112 +470,228 @@ __global__ static void k_bn_bwd(const float *__restrict__ dy, const float *__res
 }
 
 // ---- frontend convolutions (convolution.py:192-213), channel-last activations (n, t, f, c) --------------------------------------------------------
+// Work decomposition of all of them: a 256-thread block = one or a few rows (n, t); thread = four consecutive channels c4 = tid % (C / 4)
+// (16-byte accesses, a wave covers 1 KB of one position) x a position phase ph = tid / (C / 4) that strides over f.  A thread's taps stay in
+// registers over its positions; no 64-bit index arithmetic per element (the first forms of these kernels -- a grid-stride loop over flat
+// 64-bit indices with three divisions per element -- ran at 0.4 - 0.5 TB/s: 2 ms each on the 944 MB of conv.0's output at 32 x 96 x 1200).
+// C % 4 == 0 and C <= 1024 (cocr_train_begin checks).
+#define COCR_CV_ROWS 8            // rows (n, t) per block of the weight-gradient kernels = per partial sum
 // conv.0: Z1[n, t1, f1, c] = relu(b0[c] + sum_{dt,df} w0[c, dt, df] X[n, 2 f1 + df - 1, 2 t1 + dt - 1])    (X (N, H, W); zero outside)
-__global__ static void k_conv0_fwd(const float *__restrict__ X, const float *__restrict__ w0, const float *__restrict__ b0, float *__restrict__ Z1,
-                                   int N, int H, int W, int T1, int F1, int C) {
-    // a thread = one position x four consecutive channels (one 16-byte store; the nine pixels are shared by the 64 lanes of a position
-    // group; 32-bit index arithmetic, once per four outputs).  C % 4 == 0 (checked by cocr_create: multiples of 8).
-    const unsigned cq = (unsigned)C >> 2, npos = (unsigned)N * T1 * F1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)npos * cq; i += (size_t)gridDim.x * blockDim.x) {
-        const unsigned pos = (unsigned)(i / cq), c = 4 * (unsigned)(i - (size_t)pos * cq);
-        const unsigned f = pos % F1, tn = pos / F1, t = tn % T1, n = tn / T1;
-        f32x4 acc = *reinterpret_cast<const f32x4 *>(b0 + c);
-        const float *xb = X + (size_t)n * H * W;
+__global__ __launch_bounds__(256) static void k_conv0_fwd(const float *__restrict__ X, const float *__restrict__ w0, const float *__restrict__ b0,
+                                                          float *__restrict__ Z1, int N, int H, int W, int T1, int F1, int C) {
+    const unsigned C4 = (unsigned)C >> 2, FP = 256u / C4, c4 = threadIdx.x % C4, ph = threadIdx.x / C4;
+    if (ph >= FP) return;
+    const unsigned row = blockIdx.x, n = row / (unsigned)T1, t = row - n * (unsigned)T1, c = 4 * c4;
+    float w[4][9];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[q][k] = w0[(c + q) * 9 + k];
+    const f32x4 bias = *reinterpret_cast<const f32x4 *>(b0 + c);
+    const float *xb = X + (size_t)n * H * W;
+    float *zrow = Z1 + (size_t)row * F1 * C + c;
+    for (unsigned f = ph; f < (unsigned)F1; f += FP) {
+        f32x4 acc = bias;
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
             for (int df = 0; df < 3; ++df) {
-                const int col = 2 * (int)t + dt - 1, row = 2 * (int)f + df - 1;
-                if (col >= 0 && col < W && row >= 0 && row < H) {
-                    const float x = xb[(size_t)row * W + col];
+                const int col = 2 * (int)t + dt - 1, r = 2 * (int)f + df - 1;
+                if (col >= 0 && col < W && r >= 0 && r < H) {
+                    const float x = xb[(size_t)r * W + col];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w0[(c + q) * 9 + dt * 3 + df], x, acc[q]);
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[q][dt * 3 + df], x, acc[q]);
                 }
             }
-        *reinterpret_cast<f32x4 *>(Z1 + (size_t)pos * C + c) = (f32x4){fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
+        *reinterpret_cast<f32x4 *>(zrow + (size_t)f * C) = (f32x4){fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
     }
 }
-// d w0[c, tap] and d b0[c] partial sums over chunks of positions (dZ1 already masked by the ReLU): thread = c, block.y = chunk
-#define COCR_CV_POS 512
-__global__ static void k_conv0_bwd_w(const float *__restrict__ dZ1, const float *__restrict__ X, float *__restrict__ part, int N, int H, int W, int T1, int F1, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
-    if (c >= C) return;
-    const size_t npos = (size_t)N * T1 * F1, p0 = (size_t)chunk * COCR_CV_POS, p1 = min(npos, p0 + COCR_CV_POS);
-    float acc[10];
-    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    int f = (int)(p0 % F1), t = (int)((p0 / F1) % T1), n = (int)(p0 / ((size_t)F1 * T1));      // (kept by increments: no division per position)
-    for (size_t pos = p0; pos < p1; ++pos, ++f) {
-        if (f == F1) { f = 0; if (++t == T1) { t = 0; ++n; } }
-        const float d = dZ1[pos * C + c];
-        acc[9] += d;
-        for (int dt = 0; dt < 3; ++dt)
-            for (int df = 0; df < 3; ++df) {
-                const int col = 2 * t + dt - 1, row = 2 * f + df - 1;
-                if (col >= 0 && col < W && row >= 0 && row < H) acc[dt * 3 + df] = fmaf(d, X[((size_t)n * H + row) * W + col], acc[dt * 3 + df]);
-            }
+// block-level tail of the two weight-gradient kernels: acc[k][q] of every thread -> partial sums over the block's position phases,
+// part[(chunk * 10 + k) * C + c] (k < 9: taps, k == 9: bias); phases are added in ascending order (deterministic)
+__device__ __forceinline__ void conv_w_block_sum(float (&acc)[10][4], float *__restrict__ part, unsigned chunk, unsigned C, unsigned C4, unsigned FP,
+                                                 unsigned c4, unsigned ph) {
+    extern __shared__ __attribute__((aligned(16))) float cw_red[];          // [FP][10][C]
+    if (ph < FP) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) *reinterpret_cast<f32x4 *>(cw_red + ((size_t)ph * 10 + k) * C + 4 * c4) = (f32x4){acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
     }
-    for (int k = 0; k < 10; ++k) part[((size_t)chunk * 10 + k) * C + c] = acc[k];       // [chunk][tap 0..8, bias][c]
-}
-// depthwise 3x3 stride 2: Zo[n, t, f, c] = b[c] + sum w[c, dt, df] Zi[n, 2 t + dt - 1, 2 f + df - 1, c]
-__global__ static void k_dw3_fwd(const float *__restrict__ Zi, const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ Zo,
-                                 int N, int Ti, int Fi, int To, int Fo, int C) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * To * Fo * C; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C), f = (int)((i / C) % Fo), t = (int)((i / ((size_t)C * Fo)) % To), n = (int)(i / ((size_t)C * Fo * To));
-        float acc = b[c];
-        for (int dt = 0; dt < 3; ++dt)
-            for (int df = 0; df < 3; ++df) {
-                const int ti = 2 * t + dt - 1, fi = 2 * f + df - 1;
-                if (ti >= 0 && ti < Ti && fi >= 0 && fi < Fi) acc = fmaf(w[c * 9 + dt * 3 + df], Zi[(((size_t)n * Ti + ti) * Fi + fi) * C + c], acc);
-            }
-        Zo[i] = acc;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < 10 * C; i += 256) {
+        float sum = cw_red[i];
+        for (unsigned p2 = 1; p2 < FP; ++p2) sum += cw_red[(size_t)p2 * 10 * C + i];
+        part[(size_t)chunk * 10 * C + i] = sum;
     }
 }
-__global__ static void k_dw3_bwd_in(const float *__restrict__ dZo, const float *__restrict__ w, float *__restrict__ dZi, int N, int Ti, int Fi, int To, int Fo, int C) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * Ti * Fi * C; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C), fi = (int)((i / C) % Fi), ti = (int)((i / ((size_t)C * Fi)) % Ti), n = (int)(i / ((size_t)C * Fi * Ti));
-        float acc = 0.f;
-        for (int dt = 0; dt < 3; ++dt) {
-            const int t2 = ti + 1 - dt;                  // 2 t + dt - 1 = ti
-            if (t2 < 0 || (t2 & 1) || (t2 >> 1) >= To) continue;
-            for (int df = 0; df < 3; ++df) {
-                const int f2 = fi + 1 - df;
-                if (f2 < 0 || (f2 & 1) || (f2 >> 1) >= Fo) continue;
-                acc = fmaf(w[c * 9 + dt * 3 + df], dZo[(((size_t)n * To + (t2 >> 1)) * Fo + (f2 >> 1)) * C + c], acc);
+// d w0[c, tap] and d b0[c] partial sums over COCR_CV_ROWS rows (dZ1 already masked by the ReLU)
+__global__ __launch_bounds__(256) static void k_conv0_bwd_w(const float *__restrict__ dZ1, const float *__restrict__ X, float *__restrict__ part,
+                                                            int N, int H, int W, int T1, int F1, int C) {
+    const unsigned C4 = (unsigned)C >> 2, FP = 256u / C4, c4 = threadIdx.x % C4, ph = threadIdx.x / C4, c = 4 * c4;
+    float acc[10][4];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[k][q] = 0.f;
+    const unsigned row0 = blockIdx.x * COCR_CV_ROWS, row1 = min((unsigned)N * (unsigned)T1, row0 + COCR_CV_ROWS);
+    if (ph < FP) {
+        for (unsigned row = row0; row < row1; ++row) {
+            const unsigned n = row / (unsigned)T1, t = row - n * (unsigned)T1;
+            const float *xb = X + (size_t)n * H * W;
+            const float *drow = dZ1 + (size_t)row * F1 * C + c;
+            for (unsigned f = ph; f < (unsigned)F1; f += FP) {
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(drow + (size_t)f * C);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[9][q] += d[q];
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) {
+                        const int col = 2 * (int)t + dt - 1, r = 2 * (int)f + df - 1;
+                        if (col >= 0 && col < W && r >= 0 && r < H) {
+                            const float x = xb[(size_t)r * W + col];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[dt * 3 + df][q] = fmaf(d[q], x, acc[dt * 3 + df][q]);
+                        }
+                    }
             }
         }
-        dZi[i] = acc;
     }
+    conv_w_block_sum(acc, part, blockIdx.x, (unsigned)C, C4, FP, c4, ph);
 }
-__global__ static void k_dw3_bwd_w(const float *__restrict__ dZo, const float *__restrict__ Zi, float *__restrict__ part, int N, int Ti, int Fi, int To, int Fo, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
-    if (c >= C) return;
-    const size_t npos = (size_t)N * To * Fo, p0 = (size_t)chunk * COCR_CV_POS, p1 = min(npos, p0 + COCR_CV_POS);
-    float acc[10];
-    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    int f = (int)(p0 % Fo), t = (int)((p0 / Fo) % To), n = (int)(p0 / ((size_t)Fo * To));
-    for (size_t pos = p0; pos < p1; ++pos, ++f) {
-        if (f == Fo) { f = 0; if (++t == To) { t = 0; ++n; } }
-        const float d = dZo[pos * C + c];
-        acc[9] += d;
-        for (int dt = 0; dt < 3; ++dt)
+// depthwise 3x3 stride 2: Zo[n, t, f, c] = b[c] + sum w[c, dt, df] Zi[n, 2 t + dt - 1, 2 f + df - 1, c]
+__global__ __launch_bounds__(256) static void k_dw3_fwd(const float *__restrict__ Zi, const float *__restrict__ w, const float *__restrict__ b,
+                                                        float *__restrict__ Zo, int N, int Ti, int Fi, int To, int Fo, int C) {
+    const unsigned C4 = (unsigned)C >> 2, FP = 256u / C4, c4 = threadIdx.x % C4, ph = threadIdx.x / C4;
+    if (ph >= FP) return;
+    const unsigned row = blockIdx.x, n = row / (unsigned)To, t = row - n * (unsigned)To, c = 4 * c4;
+    float wt[4][9];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[q][k] = w[(c + q) * 9 + k];
+    const f32x4 bias = *reinterpret_cast<const f32x4 *>(b + c);
+    for (unsigned f = ph; f < (unsigned)Fo; f += FP) {
+        f32x4 acc = bias;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int ti = 2 * (int)t + dt - 1;
+            if (ti < 0 || ti >= Ti) continue;
+#pragma unroll
             for (int df = 0; df < 3; ++df) {
-                const int ti = 2 * t + dt - 1, fi = 2 * f + df - 1;
-                if (ti >= 0 && ti < Ti && fi >= 0 && fi < Fi) acc[dt * 3 + df] = fmaf(d, Zi[(((size_t)n * Ti + ti) * Fi + fi) * C + c], acc[dt * 3 + df]);
+                const int fi = 2 * (int)f + df - 1;
+                if (fi < 0 || fi >= Fi) continue;
+                const f32x4 z = *reinterpret_cast<const f32x4 *>(Zi + (((size_t)n * Ti + ti) * Fi + fi) * C + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(wt[q][dt * 3 + df], z[q], acc[q]);
             }
+        }
+        *reinterpret_cast<f32x4 *>(Zo + ((size_t)row * Fo + f) * C + c) = acc;
     }
-    for (int k = 0; k < 10; ++k) part[((size_t)chunk * 10 + k) * C + c] = acc[k];
 }
-// partials [chunk][10][C] -> dw[c][9] and db[c]
-__global__ static void k_conv_w_final(const float *__restrict__ part, int chunks, int C, float *__restrict__ dw, float *__restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // c * 10 + k
-    if (i >= C * 10) return;
-    const int c = i / 10, k = i - c * 10;
+// d Zi[n, ti, fi, c] = sum over the outputs (t, f) with 2 t + dt - 1 = ti, 2 f + df - 1 = fi of w[c, dt, df] dZo[n, t, f, c];
+// `relu_of`: Zi itself -- the result is masked by Zi > 0 (the ReLU that produced Zi: saves the separate pass over the largest tensor)
+__global__ __launch_bounds__(256) static void k_dw3_bwd_in(const float *__restrict__ dZo, const float *__restrict__ w, float *__restrict__ dZi,
+                                                           const float *__restrict__ relu_of, int N, int Ti, int Fi, int To, int Fo, int C) {
+    const unsigned C4 = (unsigned)C >> 2, FP = 256u / C4, c4 = threadIdx.x % C4, ph = threadIdx.x / C4;
+    if (ph >= FP) return;
+    const unsigned row = blockIdx.x, n = row / (unsigned)Ti, ti = row - n * (unsigned)Ti, c = 4 * c4;
+    float wt[4][9];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[q][k] = w[(c + q) * 9 + k];
+    for (unsigned fi = ph; fi < (unsigned)Fi; fi += FP) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int t2 = (int)ti + 1 - dt;             // 2 t + dt - 1 = ti
+            if (t2 < 0 || (t2 & 1) || (t2 >> 1) >= To) continue;
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int f2 = (int)fi + 1 - df;
+                if (f2 < 0 || (f2 & 1) || (f2 >> 1) >= Fo) continue;
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(dZo + (((size_t)n * To + (t2 >> 1)) * Fo + (f2 >> 1)) * C + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(wt[q][dt * 3 + df], d[q], acc[q]);
+            }
+        }
+        const size_t o = ((size_t)row * Fi + fi) * C + c;
+        if (relu_of) {
+            const f32x4 z = *reinterpret_cast<const f32x4 *>(relu_of + o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = z[q] > 0.f ? acc[q] : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(dZi + o) = acc;
+    }
+}
+__global__ __launch_bounds__(256) static void k_dw3_bwd_w(const float *__restrict__ dZo, const float *__restrict__ Zi, float *__restrict__ part,
+                                                          int N, int Ti, int Fi, int To, int Fo, int C) {
+    const unsigned C4 = (unsigned)C >> 2, FP = 256u / C4, c4 = threadIdx.x % C4, ph = threadIdx.x / C4, c = 4 * c4;
+    float acc[10][4];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[k][q] = 0.f;
+    const unsigned row0 = blockIdx.x * COCR_CV_ROWS, row1 = min((unsigned)N * (unsigned)To, row0 + COCR_CV_ROWS);
+    if (ph < FP) {
+        for (unsigned row = row0; row < row1; ++row) {
+            const unsigned n = row / (unsigned)To, t = row - n * (unsigned)To;
+            for (unsigned f = ph; f < (unsigned)Fo; f += FP) {
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(dZo + ((size_t)row * Fo + f) * C + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[9][q] += d[q];
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    const int ti = 2 * (int)t + dt - 1;
+                    if (ti < 0 || ti >= Ti) continue;
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) {
+                        const int fi = 2 * (int)f + df - 1;
+                        if (fi < 0 || fi >= Fi) continue;
+                        const f32x4 z = *reinterpret_cast<const f32x4 *>(Zi + (((size_t)n * Ti + ti) * Fi + fi) * C + c);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[dt * 3 + df][q] = fmaf(d[q], z[q], acc[dt * 3 + df][q]);
+                    }
+                }
+            }
+        }
+    }
+    conv_w_block_sum(acc, part, blockIdx.x, (unsigned)C, C4, FP, c4, ph);
+}
+// partials [chunk][10][C] -> dw[c][9] and db[c]: a block per 64 (k, c) entries, its 4 waves take every fourth chunk; fixed order
+__global__ __launch_bounds__(256) static void k_conv_w_final(const float *__restrict__ part, int chunks, int C, float *__restrict__ dw, float *__restrict__ db) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;      // i = k * C + c
     float s = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) s += part[((size_t)ch * 10 + k) * C + c];
-    if (k < 9) dw[c * 9 + k] = s; else db[c] = s;
+    if (i < 10 * C)
+        for (int ch = wv; ch < chunks; ch += 4) s += part[(size_t)ch * 10 * C + i];
+    red[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && i < 10 * C) {
+        const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int k = i / C, c = i - k * C;
+        if (k < 9) dw[c * 9 + k] = tot; else db[c] = tot;
+    }
 }
-// (n, t, c, f) <-> (n, t, f, c): the reference flattens the frontend output channel-major (convolution.py:235-236: feature index c F + f)
-__global__ static void k_tfc_to_tcf(const float *__restrict__ in, float *__restrict__ out, size_t NT, int F, int C, int reverse) {
+// (n, t, c, f) <-> (n, t, f, c): the reference flattens the frontend output channel-major (convolution.py:235-236: feature index c F + f).
+// A block per row (n, t): the F x C tile goes through LDS, both sides coalesced.  F * C * 4 bytes of dynamic LDS.
+__global__ __launch_bounds__(256) static void k_tfc_to_tcf(const float *__restrict__ in, float *__restrict__ out, size_t NT, int F, int C, int reverse) {
+    extern __shared__ __attribute__((aligned(16))) float tile_fc[];         // [f][c + pad]
+    const int CP = C + 1;
+    const float *src = in + (size_t)blockIdx.x * F * C;
+    float *dst = out + (size_t)blockIdx.x * F * C;
+    if (!reverse) {
+        for (int i = threadIdx.x; i < F * C; i += 256) { const int f = i / C, c = i - f * C; tile_fc[f * CP + c] = src[i]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < F * C; i += 256) { const int c = i / F, f = i - c * F; dst[i] = tile_fc[f * CP + c]; }
+    } else {
+        for (int i = threadIdx.x; i < F * C; i += 256) { const int c = i / F, f = i - c * F; tile_fc[f * CP + c] = src[i]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < F * C; i += 256) { const int f = i / C, c = i - f * C; dst[i] = tile_fc[f * CP + c]; }
+    }
+}
+
+// (the same for rows too large for LDS)
+__global__ static void k_tfc_to_tcf_flat(const float *__restrict__ in, float *__restrict__ out, size_t NT, int F, int C, int reverse) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NT * F * C; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C), f = (int)((i / C) % F);
         const size_t nt = i / ((size_t)C * F), o = (nt * C + c) * F + f;
