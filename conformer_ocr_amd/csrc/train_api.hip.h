@@ -198,7 +198,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         oTT = rsv((size_t)Z * T * Tk); oDRT = rsv((size_t)Z * R * Tk); oPmT = rsv((size_t)Hh * dh * Rk);
     }
     const size_t oZg = rsv((size_t)M * C * F), oZa = rsv(big_rows * C), oZb = rsv(big_rows * C), oZ1g = rsv((size_t)N * Ts[0] * Fs[0] * C);
-    const size_t part_floats = std::max((size_t)ceil_div((int)std::min<size_t>(big_rows, 1u << 30), COCR_CS_ROWS) * (size_t)std::max(wide, C * 10),
+    const size_t part_floats = std::max(std::max<size_t>(1024, (size_t)ceil_div((int)std::min<size_t>(big_rows, 1u << 30), 256)) * (size_t)std::max(wide, C * 10),
                                         (size_t)ceil_div(N * Ts[0], COCR_CV_ROWS) * 10 * (size_t)C);
     const size_t oPart = rsv(part_floats + 4096), oVec = rsv(4 * (size_t)std::max(D, C) + 64);
     // weight gradients are tall-K products (K = rows): split-K partial sums [splits][out x in]
@@ -262,9 +262,12 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
                            drop ? T : 0, p, (unsigned long long)seed, site);
     };
     auto colsum = [&](const float *a, const float *b, int Mr, int Nc, float *out, int accumulate) {
-        const int chunks = ceil_div(Mr, COCR_CS_ROWS);
-        hipLaunchKernelGGL(k_colsum_partial, dim3(ceil_div(Nc, 64), chunks), dim3(256), 0, s, a, b, WS(oPart), Mr, Nc);
-        hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
+        const int rows = colsum_chunk_rows(Mr), chunks = ceil_div(Mr, rows);
+        const bool vec = Nc % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0;
+        if (vec) hipLaunchKernelGGL(k_colsum_partial4, dim3(ceil_div(Nc, 256), chunks), dim3(256), 0, s, a, b, WS(oPart), Mr, Nc, rows);
+        else hipLaunchKernelGGL(k_colsum_partial, dim3(ceil_div(Nc, 64), chunks), dim3(256), 0, s, a, b, WS(oPart), Mr, Nc, rows);
+        if (vec && chunks > 32) hipLaunchKernelGGL(k_colsum_final4, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
+        else hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
     };
     // Y (rows, Nc) = X (rows, Kr) W(Nc, Kr)^T + b
     auto lin_fwd = [&](const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *Y) -> int {

@@ -58,15 +58,17 @@ __global__ static void k_pad_cols(const float *__restrict__ in, float *__restric
         out[i] = c < C ? in[(i / ldo) * C + c] : 0.f;
     }
 }
-// column sums of a (M, N) matrix, optionally of the elementwise product a .* b: part[chunk][n] over COCR_CS_ROWS-row chunks, then
+// column sums of a (M, N) matrix, optionally of the elementwise product a .* b: part[chunk][n] over chunks of `rows` rows, then
 // out[n] (+)= sum of chunks.  Fixed summation order (bit-reproducible steps): a workgroup = 64 columns x 4 row (chunk) groups, group g
 // takes every fourth row (chunk) in order, the four partial sums are added in order through LDS.  (One thread per column walking all
 // chunks serially -- the first form -- left a (9600, 256) bias gradient to ONE workgroup for 28 us, 474 times per training step.)
-#define COCR_CS_ROWS 256
-__global__ __launch_bounds__(256) static void k_colsum_partial(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N) {
+// Rows per chunk by the matrix height (colsum_chunk_rows): enough workgroups to fill the chip for the (9600, 256) bias gradients, not more
+// than ~1000 partial rows for the frontend's (230 k, 256) ones.
+static inline int colsum_chunk_rows(int M) { return M <= 16384 ? 32 : (M <= 65536 ? 64 : 256); }
+__global__ __launch_bounds__(256) static void k_colsum_partial(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N, int rows) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 64 + cl, chunk = blockIdx.y;
-    const int r0 = chunk * COCR_CS_ROWS, r1 = min(M, r0 + COCR_CS_ROWS);
+    const int r0 = chunk * rows, r1 = min(M, r0 + rows);
     float s = 0.f;
     if (n < N) {
         if (b) for (int r = r0 + rg; r < r1; r += 4) s = fmaf(a[(size_t)r * N + n], b[(size_t)r * N + n], s);
@@ -75,6 +77,21 @@ __global__ __launch_bounds__(256) static void k_colsum_partial(const float *__re
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && n < N) part[(size_t)chunk * N + n] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+}
+// the same for N % 4 == 0: a thread = four consecutive columns (16-byte loads: a wave reads 1 KB of a row, where the scalar form's 256-byte
+// pieces reached 0.55 TB/s), a workgroup = a 256-column stripe x 4 row groups
+__global__ __launch_bounds__(256) static void k_colsum_partial4(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N, int rows) {
+    __shared__ f32x4 red4[4][64];
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 256 + 4 * cq, chunk = blockIdx.y;
+    const int r0 = chunk * rows, r1 = min(M, r0 + rows);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        if (b) for (int r = r0 + rg; r < r1; r += 4) s = __builtin_elementwise_fma(*reinterpret_cast<const f32x4 *>(a + (size_t)r * N + n), *reinterpret_cast<const f32x4 *>(b + (size_t)r * N + n), s);
+        else for (int r = r0 + rg; r < r1; r += 4) s += *reinterpret_cast<const f32x4 *>(a + (size_t)r * N + n);
+    }
+    red4[rg][cq] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) *reinterpret_cast<f32x4 *>(part + (size_t)chunk * N + n) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
 }
 // out[n] (+)= sum over `chunks` of part[k][n]: the same 64 x 4 arrangement over the chunks
 __global__ __launch_bounds__(256) static void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int chunks, int N, int accumulate) {
@@ -85,6 +102,22 @@ __global__ __launch_bounds__(256) static void k_colsum_final(const float *__rest
     red[kg][cl] = s;
     __syncthreads();
     if (kg == 0 && n < N) out[n] = (accumulate ? out[n] : 0.f) + (((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]);
+}
+// the same for many chunks of a narrow matrix (N % 4 == 0): a thread = four columns, a workgroup = 64 columns x 16 chunk groups
+__global__ __launch_bounds__(256) static void k_colsum_final4(const float *__restrict__ part, float *__restrict__ out, int chunks, int N, int accumulate) {
+    __shared__ f32x4 red4[16][16];
+    const int cq = threadIdx.x & 15, kg = threadIdx.x >> 4, n = blockIdx.x * 64 + 4 * cq;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) for (int k = kg; k < chunks; k += 16) s += *reinterpret_cast<const f32x4 *>(part + (size_t)k * N + n);
+    red4[kg][cq] = s;
+    __syncthreads();
+    if (kg == 0 && n < N) {
+        f32x4 t = red4[0][cq];
+#pragma unroll
+        for (int g2 = 1; g2 < 16; ++g2) t += red4[g2][cq];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[n + q] = (accumulate ? out[n + q] : 0.f) + t[q];
+    }
 }
 
 // ---- LayerNorm (eps 1e-5): one wave per row -----------------------------------------------------------------------------------------------
