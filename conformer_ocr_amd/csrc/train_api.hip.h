@@ -206,7 +206,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     size_t split_floats = 0;
     for (auto nk : {std::pair<int, int>{ff, D}, {D, ff}, {D, D}, {2 * D, D}, {C, C}, {D, C * F}, {ncls, D}})
         split_floats = std::max(split_floats, (size_t)wg_splits(nk.first, nk.second) * nk.first * nk.second);
-    const size_t oSplit = rsv(split_floats), oLinePart = rsv((size_t)N * std::max((size_t)R * D, (size_t)D * K));
+    const size_t oSplit = rsv(split_floats), oLinePart = rsv((size_t)N * std::max((size_t)R * D, (size_t)ceil_div(T, COCR_DW_WC) * D * K));
     if (need > t->ws_bytes) {
         HIP_TRY(hipDeviceSynchronize());
         if (t->ws) (void)hipFree(t->ws);
@@ -407,7 +407,9 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         ln_fwd(WS(a.x2), key(l, "2.module.sequential.0.weight"), key(l, "2.module.sequential.0.bias"), WS(a.xn3), WS(a.mu3), WS(a.rs3));
         if ((rc = lin_fwd(WS(a.xn3), key(l, "2.module.sequential.2.conv.weight"), key(l, "2.module.sequential.2.conv.bias"), M, 2 * D, D, WS(a.ga)))) return rc;
         hipLaunchKernelGGL(k_glu_fwd, grid1(MD), dim3(256), 0, s, WS(a.ga), WS(a.g), M, D);
-        hipLaunchKernelGGL(k_dw1d_fwd, grid1(MD), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K);
+        if (K == 31) hipLaunchKernelGGL((k_dw1d_rows<false, 31>), dim3(ceil_div(D, 256), ceil_div(T, COCR_DW_TC), N), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K);
+        else if (K <= 32) hipLaunchKernelGGL((k_dw1d_rows<false, 0>), dim3(ceil_div(D, 256), ceil_div(T, COCR_DW_TC), N), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K);
+        else hipLaunchKernelGGL(k_dw1d_fwd_flat, grid1(MD), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K, 0);
         colsum(WS(a.dwo), nullptr, M, D, WS(oVec), 0);
         colsum(WS(a.dwo), WS(a.dwo), M, D, WS(oVec) + D, 0);
         hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(D, 256)), dim3(256), 0, s, WS(oVec), WS(oVec) + D, M, D, WS(a.bnm), WS(a.bnr),
@@ -472,9 +474,22 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             copy(Gp(key(l, "2.module.sequential.5.weight")), WS(oVec) + D, D);
             hipLaunchKernelGGL(k_bn_bwd, grid1(MD), dim3(256), 0, s, WS(oDc), WS(a.xhat), Pp(key(l, "2.module.sequential.5.weight")), WS(a.bnr), WS(oVec),
                                WS(oVec) + D, WS(oDe), M, D);                                                  // d dwo
-            hipLaunchKernelGGL(k_dw1d_bwd_w, dim3(ceil_div(D, 64), K, N), dim3(64), 0, s, WS(oDe), WS(a.g), WS(oLinePart), N, T, D, K);
-            hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(D * K, 64)), dim3(256), 0, s, WS(oLinePart), Gp(key(l, "2.module.sequential.4.conv.weight")), N, D * K, 0);
-            hipLaunchKernelGGL(k_dw1d_bwd_in, grid1(MD), dim3(256), 0, s, WS(oDe), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(oDc), N, T, D, K);   // d g
+            if (K <= 32) {
+                const int nch = ceil_div(T, COCR_DW_WC);
+                const dim3 gw(ceil_div(D, 256), nch, N), gr(ceil_div(D, 256), ceil_div(T, COCR_DW_TC), N);
+                const float *wdw = Pp(key(l, "2.module.sequential.4.conv.weight"));
+                float *gdw = Gp(key(l, "2.module.sequential.4.conv.weight"));
+                if (K == 31) hipLaunchKernelGGL(k_dw1d_bwd_w<31>, gw, dim3(256), 0, s, WS(oDe), WS(a.g), WS(oLinePart), N, T, D, K);
+                else hipLaunchKernelGGL(k_dw1d_bwd_w<0>, gw, dim3(256), 0, s, WS(oDe), WS(a.g), WS(oLinePart), N, T, D, K);
+                if ((D * K) % 4 == 0) hipLaunchKernelGGL(k_colsum_final4, dim3(ceil_div(D * K, 64)), dim3(256), 0, s, WS(oLinePart), gdw, N * nch, D * K, 0);
+                else hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(D * K, 64)), dim3(256), 0, s, WS(oLinePart), gdw, N * nch, D * K, 0);
+                if (K == 31) hipLaunchKernelGGL((k_dw1d_rows<true, 31>), gr, dim3(256), 0, s, WS(oDe), wdw, WS(oDc), N, T, D, K);   // d g
+                else hipLaunchKernelGGL((k_dw1d_rows<true, 0>), gr, dim3(256), 0, s, WS(oDe), wdw, WS(oDc), N, T, D, K);
+            } else {
+                hipLaunchKernelGGL(k_dw1d_bwd_w_flat, dim3(ceil_div(D, 64), K, N), dim3(64), 0, s, WS(oDe), WS(a.g), WS(oLinePart), N, T, D, K);
+                hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(D * K, 64)), dim3(256), 0, s, WS(oLinePart), Gp(key(l, "2.module.sequential.4.conv.weight")), N, D * K, 0);
+                hipLaunchKernelGGL(k_dw1d_fwd_flat, grid1(MD), dim3(256), 0, s, WS(oDe), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(oDc), N, T, D, K, 1);   // d g
+            }
             hipLaunchKernelGGL(k_glu_bwd, grid1(MD), dim3(256), 0, s, WS(a.ga), WS(oDc), WS(oDwide), M, D);                                              // d a (M, 2D)
             if ((rc = lin_bwd(WS(oDwide), WS(a.xn3), key(l, "2.module.sequential.2.conv.weight"), key(l, "2.module.sequential.2.conv.bias"), M, 2 * D, D, WS(oDc)))) return rc;
             ln_bwd(WS(oDc), WS(a.x2), WS(a.mu3), WS(a.rs3), key(l, "2.module.sequential.0.weight"), key(l, "2.module.sequential.0.bias"), dx, 1);

@@ -435,35 +435,93 @@ __global__ static void k_attn_unshift(const float *__restrict__ ds, float *__res
 }
 
 // ---- conv module: depthwise conv along time (convolution.py:140; cross-correlation, zero padding at the ends of the PADDED batch rows) --------
-__global__ static void k_dw1d_fwd(const float *__restrict__ g, const float *__restrict__ w, float *__restrict__ out, int N, int T, int D, int K) {
+// Kernel sizes up to 32 (the reference's 31): a thread = one channel of one line over a chunk of frames, its taps in registers, accumulation
+// in tap order.  grid = (ceil(D / 256), frame chunks, lines).  (The first forms -- a flat grid-stride loop with two 64-bit divisions per element
+// and a tap load per multiply, strided by K across the lanes -- took 125 us per call on (9600, 256): 12 % of the training step.)
+#define COCR_DW_TC 16             // frames per workgroup (forward / input gradient, and per partial sum of the tap gradient)
+#define COCR_DW_WC COCR_DW_TC
+// KC: the kernel size at compile time (31: the reference's), 0: K <= 32 at run time.  Frames whose whole tap range lies inside the line take
+// a branch-free path (the loads of a frame are then requested together; a uniform range test per tap kept them one behind the other).
+template <bool FLIP, int KC>      // FLIP false: out[t] = sum_tau w[tau] in[t + tau - pad];  true: out[t] = sum_tau w[tau] in[t - tau + pad] (input gradient)
+__global__ __launch_bounds__(256) static void k_dw1d_rows(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out, int N, int T, int D, int Krt) {
+    const int K = KC ? KC : Krt;
+    constexpr int KU = KC ? KC : 32;
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z, t0 = blockIdx.y * COCR_DW_TC, t1 = min(T, t0 + COCR_DW_TC), pad = (K - 1) / 2;
+    if (c >= D) return;
+    float wt[KU];
+#pragma unroll
+    for (int tau = 0; tau < KU; ++tau) wt[tau] = tau < K ? w[c * K + tau] : 0.f;
+    const float *base = in + (size_t)b * T * D + c;
+    for (int t = t0; t < t1; ++t) {
+        float acc = 0.f;
+        if (KC && t >= pad && t + pad < T) {
+            const float *p0 = base + (size_t)(FLIP ? t + pad : t - pad) * D;
+            float x[KU];
+#pragma unroll
+            for (int tau = 0; tau < KU; ++tau) x[tau] = FLIP ? p0[-(ptrdiff_t)tau * D] : p0[(size_t)tau * D];
+#pragma unroll
+            for (int tau = 0; tau < KU; ++tau) acc = fmaf(wt[tau], x[tau], acc);
+        } else {
+#pragma unroll
+            for (int tau = 0; tau < KU; ++tau)
+                if (tau < K) {
+                    const int tt = FLIP ? t - tau + pad : t + tau - pad;
+                    if (tt >= 0 && tt < T) acc = fmaf(wt[tau], base[(size_t)tt * D], acc);
+                }
+        }
+        out[((size_t)b * T + t) * D + c] = acc;
+    }
+}
+// dw[c, tau] = sum over lines and frames of dout[b, t, c] g[b, t + tau - pad, c]: partial sums per (line, chunk of COCR_DW_WC frames),
+// part[(b nch + chunk)][c K + tau], summed in order by k_colsum_final
+template <int KC>
+__global__ __launch_bounds__(256) static void k_dw1d_bwd_w(const float *__restrict__ dout, const float *__restrict__ g, float *__restrict__ part, int N, int T, int D, int Krt) {
+    const int K = KC ? KC : Krt;
+    constexpr int KU = KC ? KC : 32;
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z, t0 = blockIdx.y * COCR_DW_WC, t1 = min(T, t0 + COCR_DW_WC), pad = (K - 1) / 2;
+    if (c >= D) return;
+    float acc[KU];
+#pragma unroll
+    for (int tau = 0; tau < KU; ++tau) acc[tau] = 0.f;
+    const float *gb = g + (size_t)b * T * D + c;
+    for (int t = t0; t < t1; ++t) {
+        const float d = dout[((size_t)b * T + t) * D + c];
+        if (KC && t >= pad && t + pad < T) {
+            const float *p0 = gb + (size_t)(t - pad) * D;
+            float x[KU];
+#pragma unroll
+            for (int tau = 0; tau < KU; ++tau) x[tau] = p0[(size_t)tau * D];
+#pragma unroll
+            for (int tau = 0; tau < KU; ++tau) acc[tau] = fmaf(d, x[tau], acc[tau]);
+        } else {
+#pragma unroll
+            for (int tau = 0; tau < KU; ++tau)
+                if (tau < K) {
+                    const int tt = t + tau - pad;
+                    if (tt >= 0 && tt < T) acc[tau] = fmaf(d, gb[(size_t)tt * D], acc[tau]);
+                }
+        }
+    }
+    float *pr = part + ((size_t)b * gridDim.y + blockIdx.y) * D * K + (size_t)c * K;
+#pragma unroll
+    for (int tau = 0; tau < KU; ++tau) if (tau < K) pr[tau] = acc[tau];
+}
+// (any kernel size: the flat forms)
+__global__ static void k_dw1d_fwd_flat(const float *__restrict__ g, const float *__restrict__ w, float *__restrict__ out, int N, int T, int D, int K, int flip) {
     const int pad = (K - 1) / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * T * D; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % D), t = (int)((i / D) % T);
         const size_t base = i - (size_t)t * D;
         float acc = 0.f;
         for (int tau = 0; tau < K; ++tau) {
-            const int tt = t + tau - pad;
+            const int tt = flip ? t - tau + pad : t + tau - pad;
             if (tt >= 0 && tt < T) acc = fmaf(w[c * K + tau], g[base + (size_t)tt * D], acc);
         }
         out[i] = acc;
     }
 }
-__global__ static void k_dw1d_bwd_in(const float *__restrict__ dout, const float *__restrict__ w, float *__restrict__ dg, int N, int T, int D, int K) {
-    const int pad = (K - 1) / 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)N * T * D; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % D), t = (int)((i / D) % T);
-        const size_t base = i - (size_t)t * D;
-        float acc = 0.f;
-        for (int tau = 0; tau < K; ++tau) {
-            const int to = t - tau + pad;               // output frame whose tap tau read input frame t
-            if (to >= 0 && to < T) acc = fmaf(w[c * K + tau], dout[base + (size_t)to * D], acc);
-        }
-        dg[i] = acc;
-    }
-}
-// dw[c, tau] = sum over lines and frames of dout[b, t, c] g[b, t + tau - pad, c]: thread = (c, tau) of ONE line (blockIdx.z), frames in order;
-// part[b][c K + tau], summed over the lines by k_colsum_final
-__global__ static void k_dw1d_bwd_w(const float *__restrict__ dout, const float *__restrict__ g, float *__restrict__ part, int N, int T, int D, int K) {
+// thread = (c, tau) of ONE line (blockIdx.z), frames in order; part[b][c K + tau]
+__global__ static void k_dw1d_bwd_w_flat(const float *__restrict__ dout, const float *__restrict__ g, float *__restrict__ part, int N, int T, int D, int K) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, tau = blockIdx.y, b = blockIdx.z, pad = (K - 1) / 2;
     if (c >= D) return;
     float acc = 0.f;
