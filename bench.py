@@ -208,6 +208,7 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a captured hipGraph')
     ap.add_argument('--stagger-us', type=float, default=0.0, help='host-side offset between the first batches of a timed run (they would otherwise start in lockstep: all frontends, then all attention kernels, ... at the same time)')
+    ap.add_argument('--queue-depth', type=int, default=2, help='steps queued per stream before the host waits for the oldest (1: a stream\'s next step is launched when its previous one has been collected)')
     ap.add_argument('--streams', type=int, default=4, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL at communicator creation) go to stderr
@@ -285,7 +286,7 @@ def main():
     for e in engines:
         e.set_graph(use_graph)
 
-    def run_steps(n, nstreams, first=0):
+    def run_steps(n, nstreams, first=0, depth=None):
         """n steps; step i runs batch (first + i) % NB on stream i % nstreams (forward + greedy decode; the label records land in
         pinned host memory) and is collected nstreams steps later, so nstreams independent batches overlap on the GPU.
         Returns (lines processed, records of the last collected step)."""
@@ -300,7 +301,7 @@ def main():
                 t_end = time.perf_counter() + args.stagger_us * 1e-6
                 while time.perf_counter() < t_end:
                     pass
-            if len(pending) >= nstreams:
+            if len(pending) >= nstreams * (depth or args.queue_depth):
                 pe, h, pb = pending.pop(0)
                 recs = pe.collect(h)
                 done += batches[pb]['n']
@@ -347,10 +348,10 @@ def main():
         for rows, key in ((48, 'value_streams1'), (0, 'value_streams1_rows96')):
             eng.set_chain_rows(rows)
             torch.cuda.synchronize(dev)
-            run_steps(max(3 * NB, 6), 1)
+            run_steps(max(3 * NB, 6), 1, depth=1)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            d1, _ = run_steps(args.steps, 1)
+            d1, _ = run_steps(args.steps, 1, depth=1)
             torch.cuda.synchronize(dev)
             extra[key] = round(d1 / (time.perf_counter() - t1), 2)
         for k in range(S):
@@ -510,7 +511,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload, 'lines_per_step_per_gpu': round(lines_per_cycle / NB, 2), 'batches_in_queue': NB,
                        'gflop_per_line': round(gflop, 3), 'gflop_per_line_padded': round(padded / 1e9, 3),
-                       'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast', 'streams_per_gpu': S,
+                       'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast', 'streams_per_gpu': S, 'steps_queued_per_stream': args.queue_depth,
                        'hipgraph_replay': bool(use_graph)},
             'achieved_tflops_whole_path': round(value * gflop / 1e3, 2),
             'achieved_tflops_whole_path_padded': round(value * padded / 1e12, 2),
