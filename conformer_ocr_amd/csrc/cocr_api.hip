@@ -708,7 +708,7 @@ extern "C" int cocr_reserve(cocr_model *m, int N, int W) {
     const size_t zbytes = (size_t)N * Tz * m->feats[m->snum >= 2 ? 1 : 0] * m->C * es;
     if ((rc = ws_alloc(m, &m->z_a, zbytes))) return rc;
     if ((rc = ws_alloc(m, &m->z_b, zbytes))) return rc;
-    if ((rc = ws_alloc(m, (void **)&m->x, M * m->D * 4))) return rc;
+    if ((rc = ws_alloc(m, (void **)&m->x, (M + 128) * m->D * 4))) return rc;      // (+ 128 rows: the row-chain kernels keep the stream in whole row blocks of up to 96 rows)
     if ((rc = ws_alloc(m, &m->xn, M * m->D * es))) return rc;
     if ((rc = ws_alloc(m, &m->hid, M * m->ff * es))) return rc;
     m->qkv_bytes = (size_t)N * m->heads * Tp * m->dhp * es;
@@ -1045,7 +1045,9 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 return COCR_OK;
             };
             auto launch = [&](const ChainArgs &a) { return D == 256 ? launch_rowchain_256(s, a, taps, m->chain_rows) : launch_rowchain_512(s, a, taps, m->chain_rows); };
-            auto base = [&]() { ChainArgs a{}; a.x = x; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; a.inv_d = 1.0f / (float)m->rD; return a; };
+            // the fp32 stream between the chain launches: in the kernels' register order (ChainArgs::x_in_blocked); the first launch reads
+            // the row-major stream the frontend's reduction wrote
+            auto base = [&]() { ChainArgs a{}; a.x = x; a.x_in_blocked = 1; a.x_out_blocked = 1; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; a.inv_d = 1.0f / (float)m->rD; return a; };
             auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
                 ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha;
                 st.g1 = F32(g1); st.b1 = F32(b1); return st; };
@@ -1057,7 +1059,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 ChainStage st{}; st.kind = ST_QKV; st.W = CWT(lw.wqkv); st.bias = F32(lw.bqkv); st.N = 3 * D;
                 st.q = (bf16_t *)q; st.k = (bf16_t *)k; st.v = (bf16_t *)v; return st; };
             {   // first block's FFN + q/k/v projection on the frontend output
-                ChainArgs a = base(); a.A0 = (const bf16_t *)xn; a.nstages = 2;
+                ChainArgs a = base(); a.A0 = (const bf16_t *)xn; a.nstages = 2; a.x_in_blocked = 0;
                 a.st[0] = st_ffn(P.layers[0].ffn[0], P.layers[0].a_ln_g, P.layers[0].a_ln_b, -1, -1); a.st[0].store_x = 1;
                 a.st[1] = st_qkv(P.layers[0]);
                 a.st[0].tap_pre = tp[0];

@@ -181,7 +181,19 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     // With the depthwise prologue they are requested after it: their 8 MT NJ registers are free for the prologue (with them the ring did
     // not fit: fragments were parked in scratch memory at the kernel's start, i.e. waited for), and the first product hides them.
     f32x4 xs[MT][NJ];
+    // (blocked form: see ChainArgs::x_in_blocked)
+    const size_t xblk = ((size_t)blockIdx.x * 8 + wave) * (MT * NJ) * 256 + lane * 4;      // floats
     auto load_stream = [&]() {
+        if (p.x_in_blocked) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) {
+                    if constexpr (COCR_RC_EXP & 1) xs[i][c] = (f32x4){(float)r16, 1.f, (float)g, 0.5f};
+                    else xs[i][c] = *reinterpret_cast<const f32x4 *>(p.x + xblk + (i * NJ + c) * 256);
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const float *xrow = p.x + (size_t)min(m0 + 16 * i + r16, mend - 1) * D + 32 * wave + 4 * g;
@@ -334,6 +346,13 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     // fp32 stream -> global in the accumulator layout (16 bytes per lane, 64-byte row segments; once per launch and consumer)
     auto store_stream = [&](float *dst) {
         if constexpr (COCR_RC_EXP & 2) { asm volatile("" :: "v"(xs[0][0][0])); return; }
+        if (dst == p.x && p.x_out_blocked) {                  // (rows beyond M inside the last block carry finite values nobody uses)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) *reinterpret_cast<f32x4 *>(dst + xblk + (i * NJ + c) * 256) = xs[i][c];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             if (m0 + 16 * i + r16 < mend) {

@@ -26,6 +26,10 @@ struct ChainStage {
 struct ChainArgs {
     const bf16_t *A0;      // first operand rows (M, D) (unused with the depthwise prologue)
     float *x;              // fp32 residual stream (M, D): read at the start, written by the stages that have store_x
+    int x_in_blocked, x_out_blocked;   // the stream in the kernels' own register order instead of row-major: [row block][wave][row tile][column
+                                       // tile][lane] float4, i.e. every wave-instruction moves 1 KB of consecutive bytes (row-major, a wave's
+                                       // 16 rows x 4 lanes x 16 bytes are sixteen 64-byte pieces).  Producer and consumer must use the same
+                                       // rows per workgroup; the buffer holds whole row blocks (cocr_api: workspace).
     bf16_t *xn;            // normalised operand (M, D), written when a stage asks for it
     int M, nstages;
     const bf16_t *dw_in;   // depthwise-conv prologue: GLU output (M, D)
