@@ -440,8 +440,30 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
         l_run += __shfl_xor(l_run, 32, 64);
     }
     const float inv = 1.0f / l_run;
+    if constexpr (sizeof(T) == 2 && DHP == 64) {
+        if (dh == DHP) {
+            // the measured case (bf16, d_head 64): the wave's 16 x 128 bytes go through its shift tile (free by now; 128-byte rows, 16-byte
+            // chunks XOR-ed with row & 7) and leave as two instructions of eight whole 128-byte rows each.  Straight from the accumulators
+            // an instruction stores 16 rows x 32 bytes: four instructions that each touch all sixteen cache lines.
+            unsigned char *stg = reinterpret_cast<unsigned char *>(sk);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const f32x4 r4 = o[d] * inv;
+                const bf16x4 w = {(T)r4[0], (T)r4[1], (T)r4[2], (T)r4[3]};
+                *reinterpret_cast<bf16x4 *>(stg + il * 128 + (((2 * d + (g >> 1)) ^ (il & 7)) << 4) + 8 * (g & 1)) = w;
+            }
+            // (LDS operations of one wave execute in order: the reads below see the writes above)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 8 * j + (lane >> 3), ch = lane & 7;
+                const bf16x8 v8 = *reinterpret_cast<const bf16x8 *>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+                if (i0 + row < Tn) *reinterpret_cast<bf16x8 *>(ctx + ((size_t)b * Tn + i0 + row) * (heads * DHP) + hh * DHP + 8 * ch) = v8;
+            }
+            return;
+        }
+    }
     if (dh == DHP) {
-        // common case (no padded head dims): straight-line 8-/16-byte stores, rows beyond T go to nowhere by predication only
+        // no padded head dims: straight-line 8-/16-byte stores, rows beyond T go to nowhere by predication only
         if (i0 + il < Tn) {
             T *dst = ctx + ((size_t)b * Tn + i0 + il) * (heads * DHP) + hh * DHP + 4 * g;
 #pragma unroll
