@@ -36,7 +36,7 @@
 #include "rowchain_args.hip.h"
 
 #ifndef COCR_RC_EXP
-#define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs
+#define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs, 16 no SiLU transcendentals
 #endif
 
 // Lane-swap butterflies (gfx950).  v_permlane32_swap a, b: a <- [a.lo32, b.lo32], b <- [a.hi32, b.hi32]; v_permlane16_swap a, b (rows of 16
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const int tau = rin - i;
-                            if (tau >= 0 && tau < DWK) acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]);
+                            if (tau >= 0 && tau < DWK) { if constexpr (COCR_RC_EXP & 8) { if (tau == 0) acc[i] += xf; } else acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]); }
                         }
                     }
                 } else {                                               // near a line end: tap tau of row i is in range iff 0 <= t_i + tau - PAD < T
@@ -515,8 +515,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                 for (int h = 0; h < 2; ++h) {
                     const f32x2_t v = {v4[2 * h], v4[2 * h + 1]};
                     f32x2_t e = v * (f32x2_t){-1.44269504088896340736f, -1.44269504088896340736f};
-                    e = (f32x2_t){__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + (f32x2_t){1.0f, 1.0f};
-                    const f32x2_t o = v * (f32x2_t){__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                    if constexpr (!(COCR_RC_EXP & 16)) e = (f32x2_t){__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + (f32x2_t){1.0f, 1.0f};
+                    const f32x2_t o = (COCR_RC_EXP & 16) ? v * e : v * (f32x2_t){__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
                     packed[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
                 }
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
