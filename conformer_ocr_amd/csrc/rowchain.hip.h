@@ -36,7 +36,8 @@
 #include "rowchain_args.hip.h"
 
 #ifndef COCR_RC_EXP
-#define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs, 16 no SiLU transcendentals
+#define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs, 16 no SiLU transcendentals,
+                               // 32 no LayerNorm statistics, 64 no matrix instructions, 128 no weight stream (the ring is loaded once), 256 one operand fragment set per step
 #endif
 
 // Lane-swap butterflies (gfx950).  v_permlane32_swap a, b: a <- [a.lo32, b.lo32], b <- [a.hi32, b.hi32]; v_permlane16_swap a, b (rows of 16
@@ -300,15 +301,24 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             for (int h0 = 0; h0 < MT; h0 += HT) {
                 bf16x8 a[HT];
 #pragma unroll
-                for (int i = 0; i < HT; ++i) a[i] = lds_frag_swz(img + (kk >> 1) * PANEL + (16 * (h0 + i) + r16) * 128, kk & 1, g, swz, T());
+                for (int i = 0; i < HT; ++i) {
+                    if constexpr (COCR_RC_EXP & 256) { if (kk == 0) a[i] = lds_frag_swz(img + (16 * (h0 + i) + r16) * 128, 0, g, swz, T()); else asm volatile("" : "+v"(a[i])); }
+                    else a[i] = lds_frag_swz(img + (kk >> 1) * PANEL + (16 * (h0 + i) + r16) * 128, kk & 1, g, swz, T());
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < HT; ++i)
-                        acc[h0 + i][c0 + j] = mma16(ring[2 * kk + j], a[i], (fresh && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[h0 + i][c0 + j]);
+                    for (int i = 0; i < HT; ++i) {
+                        if constexpr (COCR_RC_EXP & 64) {
+                            if (fresh && kk == 0) acc[h0 + i][c0 + j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            asm volatile("" : "+v"(acc[h0 + i][c0 + j]) : "v"(ring[2 * kk + j]), "v"(a[i]));
+                        } else acc[h0 + i][c0 + j] = mma16(ring[2 * kk + j], a[i], (fresh && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[h0 + i][c0 + j]);
+                    }
             }
-            fill(nxt, 2 * kk);
-            fill(nxt, 2 * kk + 1);
+            if constexpr (!(COCR_RC_EXP & 128)) {
+                fill(nxt, 2 * kk);
+                fill(nxt, 2 * kk + 1);
+            }
             side(kk);
             __builtin_amdgcn_sched_barrier(0);               // keep the refill (and the side work) here: the scheduler otherwise sinks all of it to the step's end
         }
@@ -366,6 +376,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     // partials (sum, sum of squares) in LDS at `pbuf` [row][wave], one barrier, then every lane adds the 8 waves' partials of its MT rows.
     // One pass (E[x^2] - mean^2 in fp32 over D <= 512 values of magnitude ~1: the bf16 operand this feeds has 8 significant bits).
     auto row_stats = [&](unsigned char *pbuf, bool wait_params, float (&mean)[MT], float (&rstd)[MT]) {
+        if constexpr (COCR_RC_EXP & 32) { for (int i = 0; i < MT; ++i) { mean[i] = 0.f; rstd[i] = 1.f; } lds_fence_barrier(); return; }
         float s[MT], ss[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
