@@ -37,7 +37,8 @@
 
 #ifndef COCR_RC_EXP
 #define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs, 16 no SiLU transcendentals,
-                               // 32 no LayerNorm statistics, 64 no matrix instructions, 128 no weight stream (the ring is loaded once), 256 one operand fragment set per step
+                               // 32 no LayerNorm statistics, 64 no matrix instructions, 128 no weight stream (the ring is loaded once), 256 one operand fragment set per step,
+                               // 512 no barriers, 1024 no q/k/v staging and copy-out, 2048 no depthwise prologue arithmetic at all, 4096 no SiLU tiles, 8192 no normalise
 #endif
 
 // Lane-swap butterflies (gfx950).  v_permlane32_swap a, b: a <- [a.lo32, b.lo32], b <- [a.hi32, b.hi32]; v_permlane16_swap a, b (rows of 16
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     RSTAMP()                                       // 0: start
     auto lds_fence_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(COCR_RC_EXP & 512)) __builtin_amdgcn_s_barrier();
     };
 
     constexpr int DWPAD = DWK ? (DWK - 1) / 2 : 0, DWROWS = BMC + 2 * DWPAD;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             // rows of this thread: quarter rq of the block, in groups of 8 (a ragged last group re-does rows of the previous one)
             constexpr int RQ = BMC / 4;
 #pragma unroll 1
-            for (int r0 = RQ * rq; r0 < RQ * (rq + 1); r0 += 8) {
+            for (int r0 = RQ * rq; r0 < ((COCR_RC_EXP & 2048) ? RQ * rq : RQ * (rq + 1)); r0 += 8) {
                 const int rb = min(r0, RQ * (rq + 1) - 8);
                 const int t0 = __builtin_amdgcn_readfirstlane(tpos[rb]);
                 f32x2_t acc[8];
@@ -258,16 +259,38 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                             if (tau >= 0 && tau < DWK) { if constexpr (COCR_RC_EXP & 8) { if (tau == 0) acc[i] += xf; } else acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]); }
                         }
                     }
-                } else {                                               // near a line end: tap tau of row i is in range iff 0 <= t_i + tau - PAD < T
+                } else if (__builtin_amdgcn_readfirstlane(tpos[rb + 7]) == t0 + 7) {
+                    // near a line end, the 8 rows inside one line: the same walk over the window with the rows outside the line read as zero
+                    // (a zero tap product leaves the sum as it is: the same values as skipping the tap).  The per-tap form below costs 3 x
+                    // the instructions; with one line end per three 96-row blocks it set the kernel's duration: the launch is as long as its
+                    // slowest workgroup (timing experiment without the prologue's arithmetic: - 11 us of 63).
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int ti = __builtin_amdgcn_readfirstlane(tpos[rb + i]);
+                    for (int rin = 0; rin < 8 + DWK - 1; ++rin) {
+                        const bool ok = (unsigned)(t0 + rin - DWPAD) < (unsigned)T_;     // (uniform)
+                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * 512);
+                        const f32x2_t xf = {ok ? (float)xv[0] : 0.f, ok ? (float)xv[1] : 0.f};
 #pragma unroll
-                        for (int tau = 0; tau < DWK; ++tau) {
-                            const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + (i + tau) * 512);
-                            const bool ok = (unsigned)(ti + tau - DWPAD) < (unsigned)T_;
-                            const f32x2_t xf = {ok ? (float)xv[0] : 0.f, ok ? (float)xv[1] : 0.f};
-                            acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]);
+                        for (int i = 0; i < 8; ++i) {
+                            const int tau = rin - i;
+                            if (tau >= 0 && tau < DWK) acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]);
+                        }
+                    }
+                } else {                                               // rows of two lines: tap tau of row i is in range iff 0 <= t_i + tau - PAD < T
+                    int ti[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ti[i] = __builtin_amdgcn_readfirstlane(tpos[rb + i]);
+#pragma unroll
+                    for (int rin = 0; rin < 8 + DWK - 1; ++rin) {      // the same walk, the window row masked per output row
+                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * 512);
+                        const f32x2_t xr = {(float)xv[0], (float)xv[1]};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int tau = rin - i;
+                            if (tau >= 0 && tau < DWK) {
+                                const bool ok = (unsigned)(ti[i] + tau - DWPAD) < (unsigned)T_;
+                                const f32x2_t xf = {ok ? xr[0] : 0.f, ok ? xr[1] : 0.f};
+                                acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]);
+                            }
                         }
                     }
                 }
@@ -416,6 +439,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     // (chained LayerNorms); otherwise the result goes to the operand image (and the stream stays).
     auto normalise = [&](int which, const float (&mean)[MT], const float (&rstd)[MT], auto IN_PLACE) {
         constexpr bool in_place = decltype(IN_PLACE)::value;
+        if constexpr (COCR_RC_EXP & 8192) return;
         const float *ga = lnp + which * 2 * D, *be = ga + D;
 #pragma unroll
         for (int c = 0; c < NJ; ++c) {
@@ -511,6 +535,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             f32x4 acc1[MT][2];
             Bias2 bb;
             auto silu_tile = [&](int tIdx, unsigned char *hb, auto PIN) {  // tile t = (row tile t / 2, column tile t % 2) of acc1 -> hb
+                if constexpr (COCR_RC_EXP & 4096) return;
                 const int i = tIdx >> 1, j = tIdx & 1;
                 // PIN: called from a k-step -- the arithmetic below is pure, and instruction selection otherwise gathers all twelve tiles'
                 // worth of it in one block ahead of the product's first k-step (seen in the ISA: only the LDS stores stayed inside the
@@ -622,6 +647,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                     else step(xa + ks * 4 * PANEL, acc, 0, nxt, no_side, std::false_type{});
                 }
                 unsigned char *tile = hs + (s3 & 1) * (BMC * OS);
+                if constexpr (COCR_RC_EXP & 1024) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[MT - 1][1])); continue; }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
