@@ -35,10 +35,13 @@
 #include "gemm.hip.h"
 #include "rowchain_args.hip.h"
 
+#ifndef COCR_STAMP_WG
+#define COCR_STAMP_WG 7        // dev (stamps build): the workgroup whose phase boundaries are stamped
+#endif
 #ifndef COCR_RC_EXP
 #define COCR_RC_EXP 0          // dev: timing experiments (wrong results): 1 no stream load, 2 no stream store, 4 no partial read-back, 8 no depthwise FMAs, 16 no SiLU transcendentals,
                                // 32 no LayerNorm statistics, 64 no matrix instructions, 128 no weight stream (the ring is loaded once), 256 one operand fragment set per step,
-                               // 512 no barriers, 1024 no q/k/v staging and copy-out, 2048 no depthwise prologue arithmetic at all, 4096 no SiLU tiles, 8192 no normalise
+                               // 512 no barriers, 1024 no q/k/v staging and copy-out, 2048 no depthwise prologue arithmetic at all, 4096 no SiLU tiles, 8192 no normalise, 16384 no SiLU in the depthwise prologue
 #endif
 
 // Lane-swap butterflies (gfx950).  v_permlane32_swap a, b: a <- [a.lo32, b.lo32], b <- [a.hi32, b.hi32]; v_permlane16_swap a, b (rows of 16
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     const int lrow = lane >> 3, cpos = lane & 7;
 #ifdef COCR_CHAIN_STAMPS_BUILD
     int sk = 0;
-#define RSTAMP() { if (p.stamps && blockIdx.x == 7 && lane == 0) p.stamps[wave * 64 + sk] = __builtin_readcyclecounter(); ++sk; }
+#define RSTAMP() { if (p.stamps && blockIdx.x == COCR_STAMP_WG && lane == 0) p.stamps[wave * 64 + sk] = __builtin_readcyclecounter(); ++sk; }
 #else
 #define RSTAMP()
 #endif
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = rb + i, cc = h * 256 + c;
-                    const bf16x2 o = {(T)silu_f(acc[i][0]), (T)silu_f(acc[i][1])};
+                    const bf16x2 o = (COCR_RC_EXP & 16384) ? (bf16x2){(T)acc[i][0], (T)acc[i][1]} : (bf16x2){(T)silu_f(acc[i][0]), (T)silu_f(acc[i][1])};
                     *reinterpret_cast<bf16x2 *>(xa + (cc >> 6) * PANEL + row * 128 + ((((cc & 63) >> 3) ^ (row & 7)) << 4) + (cc & 7) * 2) = o;
                     if constexpr (TAPS) {
                         if (p.tap_dw && m0 + row < mend) *reinterpret_cast<bf16x2 *>(p.tap_dw + (size_t)(m0 + row) * D + cc) = o;
