@@ -38,6 +38,10 @@ __device__ __forceinline__ float max3_f(float a, float b, float c) {
     return r;
 }
 
+#ifndef COCR_ATT_EXP
+#define COCR_ATT_EXP 0          // dev: timing experiments (wrong results): 1 no shift through LDS, 2 no positional products, 4 no exponentials,
+                               // 8 no P.V products, 16 tiles staged once, 32 no content products, 64 no barriers
+#endif
 #define COCR_POS_MAXLEN 5000        // the reference's RelPositionalEncoding(max_len): 2 * max_len - 1 table rows, row max_len - 1 <-> relative position 0
 
 // V^T fragment of one k-chunk (32 keys) for head-dim row tile d: element e of quad g <-> key 16 (e>>2) + 4g + (e&3)
@@ -138,7 +142,10 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
     for (int it = 0; it < KV_IT; ++it) { const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR; kvoff[it] = (unsigned)row * RB + ch * 16; }
 #pragma unroll
     for (int it = 0; it < P_IT; ++it) { const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR; poff[it] = (unsigned)row * (unsigned)prow * (unsigned)sizeof(T) + ch * 16; }
-    auto load_tile = [&](int j0) {
+    // The band of consecutive key tiles overlaps by half (it moves by 64 rows per tile): the 128 band rows in LDS are a ring, local band row
+    // lr of tile t sits in slot (lr + 64 (t & 1)) & 127, and every tile after the first stages only its 64 new rows (24 KB instead of 32 KB
+    // per tile through the memory pipeline: staging is a quarter of this kernel's time, timing experiment COCR_ATT_EXP=16).
+    auto load_tile = [&](int j0, bool first) {
         const unsigned char *kt = reinterpret_cast<const unsigned char *>(kbase) + (size_t)j0 * RB;
         const unsigned char *vt = reinterpret_cast<const unsigned char *>(vbase) + (size_t)j0 * RB;
         const unsigned char *pt = reinterpret_cast<const unsigned char *>(pbase) + (size_t)(pos_center - (i0b + 63) + j0) * prow * sizeof(T);
@@ -148,9 +155,9 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             rv[it] = *reinterpret_cast<const u32x4 *>(vt + kvoff[it]);
         }
 #pragma unroll
-        for (int it = 0; it < P_IT; ++it) rp[it] = *reinterpret_cast<const u32x4 *>(pt + poff[it]);
+        for (int it = 0; it < P_IT; ++it) if (first || it >= P_IT / 2) rp[it] = *reinterpret_cast<const u32x4 *>(pt + poff[it]);
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int t) {
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {
             const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
@@ -160,11 +167,12 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
         }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
-            const int id = it * 256 + tid, row = id / CPR, ch = id - row * CPR;
+            if (t > 0 && it < P_IT / 2) continue;           // (uniform) rows 0..63 of this tile's band are rows 64..127 of the previous one's
+            const int id = it * 256 + tid, lr = id / CPR, ch = id - lr * CPR, row = (lr + 64 * (t & 1)) & 127;
             *reinterpret_cast<u32x4 *>(ps + row * RS + (SWZ ? (ch ^ (row & 7)) : ch) * 16) = rp[it];
         }
     };
-    load_tile(0);
+    load_tile(0, true);
 
     // B operands: (q + u) and (q + v) of this lane's query, per k-chunk; padded dims stay zero.  All loads (q fragments
     // and the 8 consecutive bias values of each) are issued before the first use: one round trip, not one per element.
@@ -238,12 +246,13 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 
     stamp();
     for (int j0 = 0; j0 < Tn; j0 += 64) {
-        __syncthreads();                       // every wave is done with the previous tile
+        if constexpr (!(COCR_ATT_EXP & 64)) __syncthreads();                       // every wave is done with the previous tile
         stamp();
-        store_tile();
-        __syncthreads();
+        const int bslot = 64 * ((j0 >> 6) & 1);    // ring offset of this tile's band rows
+        if (!(COCR_ATT_EXP & 16) || j0 == 0) store_tile(j0 >> 6);
+        if constexpr (!(COCR_ATT_EXP & 64)) __syncthreads();
         stamp();
-        load_tile(j0 + 64 < Tn ? j0 + 64 : j0);   // in flight during the compute below (unconditional: the staging registers stay registers)
+        if (!(COCR_ATT_EXP & 16)) load_tile(j0 + 64 < Tn ? j0 + 64 : j0, false);   // in flight during the compute below (unconditional: the staging registers stay registers)
         if constexpr (MERGE) {
             // ---- one softmax step per 64-key tile: the two 32-key halves still take the shift tile in turn (it holds 48 band rows),
             // but the cross-lane maximum (two dependent ds_bpermute round trips), the rescale test, the exponentials and the P.V
@@ -263,26 +272,33 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                     if (half == 1 && ml == 0) rr = keep;
                     else {
                         rr = negm4;
-                        const unsigned char *pr = ps + (lb0 + 16 * (2 * half + ml) + il) * RS;
+                        const unsigned char *pr = ps + ((lb0 + 16 * (2 * half + ml) + il + bslot) & 127) * RS;
+                        if constexpr (!(COCR_ATT_EXP & 2)) {
 #pragma unroll
-                        for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr + frag_off(c))), qv[c], rr);
+                            for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr + frag_off(c))), qv[c], rr); }
                     }
                     if (half == 0 && ml == 2) keep = rr;
+                    if constexpr (COCR_ATT_EXP & 1) { if (ml < 2) sc[2 * half + ml] = rr; }
+                    else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sk[(16 * ml + 4 * g + r) * SK + il] = rr[r];
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the shift tile is private to the wave; its LDS operations execute in order
+                if constexpr (!(COCR_ATT_EXP & 1)) {
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sc[2 * half + tl][r] = sk[(15 - il + 16 * tl + 4 * g + r) * SK + il];
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the tile is overwritten
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl) {
                     const int tt = 2 * half + tl;
                     const unsigned char *kr = ks + (16 * tt + il) * RS;
+                    if constexpr (!(COCR_ATT_EXP & 32)) {
 #pragma unroll
-                    for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]);
+                        for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]); }
                 }
             }
             // sc = score - m_run (log2 units)
@@ -330,13 +346,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pb[tt >> 1][4 * (tt & 1) + r] = from_f32<T>(__builtin_amdgcn_exp2f(sc[tt][r]));
+                for (int r = 0; r < 4; ++r) pb[tt >> 1][4 * (tt & 1) + r] = from_f32<T>((COCR_ATT_EXP & 4) ? sc[tt][r] : __builtin_amdgcn_exp2f(sc[tt][r]));
             // the softmax denominators on the matrix cores as well: one more row tile whose row 0 is all ones (2 MFMAs per key tile
             // instead of 16 VALU adds; the sum is over the SAME bf16-rounded probabilities the numerator uses)
             osum = mma16(ones, pb[0], osum);
             osum = mma16(ones, pb[1], osum);
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
+                if constexpr (COCR_ATT_EXP & 8) { asm volatile("" : "+v"(o[d]) : "v"(pb[0]), "v"(pb[1])); continue; }
                 o[d] = mma16(load_vt_frag<SWZ>(vs, RS, 0, d, il, g, T()), pb[0], o[d]);
                 o[d] = mma16(load_vt_frag<SWZ>(vs, RS, 32, d, il, g, T()), pb[1], o[d]);
             }
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) {
                 f32x4 rr = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const unsigned char *pr = ps + (lb + 16 * mt + il) * RS;
+                const unsigned char *pr = ps + ((lb + 16 * mt + il + bslot) & 127) * RS;
 #pragma unroll
                 for (int c = 0; c < KC; ++c) rr = mma16(load_frag(reinterpret_cast<const T *>(pr + frag_off(c))), qv[c], rr);
 #pragma unroll
