@@ -286,6 +286,7 @@ def main():
     for e in engines:
         e.set_graph(use_graph)
 
+    _times = []
     def run_steps(n, nstreams, first=0, depth=None):
         """n steps; step i runs batch (first + i) % NB on stream i % nstreams (forward + greedy decode; the label records land in
         pinned host memory) and is collected nstreams steps later, so nstreams independent batches overlap on the GPU.
@@ -304,9 +305,11 @@ def main():
             if len(pending) >= nstreams * (depth or args.queue_depth):
                 pe, h, pb = pending.pop(0)
                 recs = pe.collect(h)
+                _times.append(time.perf_counter())
                 done += batches[pb]['n']
         for pe, h, pb in pending:
             recs = pe.collect(h)
+            _times.append(time.perf_counter())
             done += batches[pb]['n']
         return done, recs
 
@@ -331,6 +334,8 @@ def main():
     done, recs = run_steps(args.steps, S)
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get('COCR_BENCH_TIMES'):
+        sys.stderr.write('completion times (ms after t0): ' + ' '.join(f'{(x - t0) * 1e3:.2f}' for x in _times[-args.steps:]) + f' | end {dt * 1e3:.2f}\n')
     if use_dist:
         t = torch.tensor([dt, float(done)], dtype=torch.float64, device=dev)
         tmax = t.clone()
