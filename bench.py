@@ -209,6 +209,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from the host instead of replaying a captured hipGraph')
     ap.add_argument('--stagger-us', type=float, default=0.0, help='host-side offset between the first batches of a timed run (they would otherwise start in lockstep: all frontends, then all attention kernels, ... at the same time)')
     ap.add_argument('--queue-depth', type=int, default=2, help='steps queued per stream before the host waits for the oldest (1: a stream\'s next step is launched when its previous one has been collected)')
+    ap.add_argument('--private-weights', action='store_true', help='every packed model copy holds its own weights (the form before cocr_share_weights)')
     ap.add_argument('--streams', type=int, default=4, help='independent batches in flight (one packed model + HIP stream each)')
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL at communicator creation) go to stderr
@@ -241,16 +242,22 @@ def main():
     state = None
     if rank == 0:
         state = fix['state'] if fix else synth.make_state_dict(hp, seed=1236, decoder_gain=8.0)
-        for e in engines:
-            e.load_state(state)
-            e.finalize()
+        eng.load_state(state)
+        eng.finalize()
     else:
-        for e in engines:
-            e.finalize_empty()
+        eng.finalize_empty()
     if use_dist:
         from conformer_ocr_amd.dist import broadcast_weights
-        for e in engines:
-            broadcast_weights(e, src=0)
+        broadcast_weights(eng, src=0)
+    if not args.private_weights:
+        for e in engines[1:]:
+            e.share_weights(eng)          # one set of weights and tables per GPU: the packed copies differ in workspace and captured launches only
+    else:                                 # (every copy its own weights: 4 x ~100 MB no longer fit the Infinity Cache)
+        blob = eng.export_blob()
+        for e in engines[1:]:
+            e.finalize_empty()
+            e.import_blob(blob)
+        torch.cuda.synchronize(dev)
 
     # ---- per-rank independent batches, resident in HBM (float32 (N,H,W): what the reference's loader hands over, cli/test.py:189)
     if args.config == 'cfg4':
@@ -294,7 +301,7 @@ def main():
         pending, recs, done = [], None, 0
         for i in range(n):
             k, b = i % nstreams, (first + i) % NB
-            e = engines[k]
+            e = engines[(i % S) if os.environ.get('COCR_BENCH_ALT') else k]      # dev: COCR_BENCH_ALT=1 cycles the packed model copies on however few streams
             with torch.cuda.stream(streams[k]):
                 logits, out_lens = e.forward(batches[b]['x'], batches[b]['lens'], out=outs[k][b])
                 pending.append((e, e.ctc_greedy_async(logits, out_lens), b))

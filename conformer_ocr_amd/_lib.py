@@ -38,6 +38,7 @@ SYMBOLS = {
     'cocr_blob_export': (_I, [_P, _P, C.c_size_t, _P]),
     'cocr_blob_import': (_I, [_P, _P, C.c_size_t, _P]),
     'cocr_out_len': (C.c_int32, [C.c_int32, C.c_int32]),
+    'cocr_share_weights': (_I, [_P, _P]),
     'cocr_collate_lines': (_I, [C.POINTER(_P), _I32P, _I, _I, _I, _P, _I, _I]),
     'cocr_reserve': (_I, [_P, _I, _I]),
     'cocr_forward': (_I, [_P, _P, _I, _I, _I, _I, _I32P, _P, _I32P, _P]),

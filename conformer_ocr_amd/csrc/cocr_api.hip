@@ -107,6 +107,11 @@ struct cocr_model {
     unsigned char *ptab = nullptr;
     size_t ptab_stride = 0;
     bool ptab_stale = true;
+    // cocr_share_weights: this model reads `owner`'s blob / packed copies / tables instead of holding its own (several packed copies of one
+    // model, each with its workspace, for callers that keep several batches in flight: four private copies are 4 x ~100 MB, more than the
+    // 256 MB Infinity Cache -- every forward then streamed its weights from HBM).  `wgen`: bumped whenever the owner's buffers may have moved.
+    cocr_model *owner = nullptr;
+    unsigned long long wgen = 1, seen_wgen = 0;
     // workspace
     int capN = 0, capW = 0;
     std::vector<void *> ws_allocs;
@@ -277,10 +282,12 @@ extern "C" void cocr_destroy(cocr_model *m) {
     train_free(m);
     free_workspace(m);
     clear_taps(m);
-    if (m->blob) (void)hipFree(m->blob);
-    if (m->packed) (void)hipFree(m->packed);
-    if (m->ptab) (void)hipFree(m->ptab);
-    if (m->fpack) (void)hipFree(m->fpack);
+    if (!m->owner) {
+        if (m->blob) (void)hipFree(m->blob);
+        if (m->packed) (void)hipFree(m->packed);
+        if (m->ptab) (void)hipFree(m->ptab);
+        if (m->fpack) (void)hipFree(m->fpack);
+    }
     if (m->pre_buf) (void)hipFree(m->pre_buf);
     if (m->stamps) {
         (void)hipDeviceSynchronize();
@@ -476,6 +483,8 @@ static int alloc_blob(cocr_model *m, int dtype) {
     if (dtype != COCR_BF16 && dtype != COCR_F32) return fail(COCR_EINVAL, "compute dtype must be COCR_BF16 or COCR_F32");
     HIP_TRY(hipSetDevice(m->device));
     { const int rc = set_engine_dims(m, dtype); if (rc) return rc; }
+    if (m->owner) { m->owner = nullptr; m->blob = m->packed = m->ptab = nullptr; m->fpack = nullptr; }      // weights of its own again
+    m->wgen++;
     if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
     if (m->packed) { (void)hipFree(m->packed); m->packed = nullptr; }
     if (m->ptab) { (void)hipFree(m->ptab); m->ptab = nullptr; }
@@ -498,9 +507,32 @@ extern "C" int cocr_finalize_empty(cocr_model *m, int compute_dtype) {
     return COCR_OK;
 }
 
+extern "C" int cocr_share_weights(cocr_model *m, cocr_model *owner) {
+    if (!m || !owner || m == owner) return fail(COCR_EINVAL, "two different models expected");
+    if (owner->owner) return fail(COCR_EINVAL, "the owner itself shares another model's weights");
+    if (owner->dtype < 0 || !owner->blob) return fail(COCR_ESTATE, "the owner is not finalized");
+    if (m->device != owner->device || memcmp(&m->hp, &owner->hp, sizeof m->hp) != 0) return fail(COCR_EINVAL, "models of the same hyper-parameters on the same device expected");
+    if (m->train || owner->train) return fail(COCR_ESTATE, "not while a training state exists");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (m->dtype != owner->dtype || !m->blob || m->owner) { const int rc = alloc_blob(m, owner->dtype); if (rc) return rc; }     // dims, plan
+    (void)hipFree(m->blob);
+    if (m->packed) (void)hipFree(m->packed);
+    if (m->ptab) (void)hipFree(m->ptab);
+    if (m->fpack) (void)hipFree(m->fpack);
+    m->blob = m->packed = m->ptab = nullptr; m->fpack = nullptr;
+    m->owner = owner;
+    m->seen_wgen = 0;                               // the next forward adopts the owner's pointers
+    m->blob = owner->blob;                          // ("finalized" tests look at it)
+    for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear(); m->graph_seen.clear();
+    return COCR_OK;
+}
+
 extern "C" int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes) {
     if (!m || !device_ptr || !bytes) return fail(COCR_EINVAL, "null argument");
     if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (m->owner) return fail(COCR_ESTATE, "this model shares another model's weights: address the owner");
     *device_ptr = m->blob;
     *bytes = m->plan.total;
     m->packed_stale = m->ptab_stale = true;          // the caller may write through the pointer: derived copies are rebuilt by the next forward
@@ -521,6 +553,7 @@ extern "C" int cocr_blob_import(cocr_model *m, const void *src_device, size_t by
     if (!m || !src_device) return fail(COCR_EINVAL, "null argument");
     if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
     if (bytes != m->plan.total) return fail(COCR_EINVAL, "blob is %zu bytes, buffer %zu", m->plan.total, bytes);
+    if (m->owner) return fail(COCR_ESTATE, "this model shares another model's weights: address the owner");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(m->blob, src_device, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     m->packed_stale = m->ptab_stale = true;
@@ -1238,13 +1271,15 @@ static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N
         // a position's encoding does not depend on the table length, so shorter lines keep their results)
         const int Tp64 = round_up(cocr_out_len(W, m->hp.subsampling_factor), 64);
         if (Tp64 > 65536) return fail(COCR_EUNSUPPORTED, "more than 65536 output frames");
-        if (Tp64 + 64 > m->pos_maxlen) {
+        cocr_model *root = m->owner ? m->owner : m;      // whose tables these are
+        if (Tp64 + 64 > root->pos_maxlen) {
             HIP_TRY(hipDeviceSynchronize());
             for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);      // captured launches point at the old tables
             m->graphs.clear(); m->graph_seen.clear();
-            if (m->ptab) { (void)hipFree(m->ptab); m->ptab = nullptr; }
-            m->pos_maxlen = round_up(Tp64 + 64, 1024);
-            m->ptab_stale = true;
+            if (root->ptab) { (void)hipFree(root->ptab); root->ptab = nullptr; }
+            root->pos_maxlen = round_up(Tp64 + 64, 1024);
+            root->ptab_stale = true;
+            root->wgen++;
         }
     }
     int rc = cocr_reserve(m, N, W);
@@ -1252,7 +1287,33 @@ static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N
     if (in_lens && out_lens)
         for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = ensure_packed(m, s)) || (rc = ensure_ptab(m, s))) return rc;
+    if (m->owner) {
+        // shared weights: the derived copies are the owner's; rebuilt (rarely: new weights, longer tables) with the device idle, because
+        // other models that share them run on other streams; then this model's view of the pointers is refreshed
+        cocr_model *o = m->owner;
+        if (o->packed_stale || o->ptab_stale) {
+            HIP_TRY(hipDeviceSynchronize());
+            if ((rc = ensure_packed(o, s)) || (rc = ensure_ptab(o, s))) return rc;
+            HIP_TRY(hipDeviceSynchronize());
+            o->wgen++;
+        }
+        if (m->seen_wgen != o->wgen) {
+            m->blob = o->blob; m->packed = o->packed; m->fpack = o->fpack; m->ptab = o->ptab; m->ptab_stride = o->ptab_stride; m->pos_maxlen = o->pos_maxlen;
+            m->packed_stale = m->ptab_stale = false;
+            m->seen_wgen = o->wgen;
+            for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);      // captured launches may point at moved buffers
+            m->graphs.clear(); m->graph_seen.clear();
+        }
+    } else {
+        const bool rebuilt = m->packed_stale || m->ptab_stale;
+        if (rebuilt && m->wgen > 1) HIP_TRY(hipDeviceSynchronize());       // (models may share these buffers: cocr_share_weights)
+        if ((rc = ensure_packed(m, s)) || (rc = ensure_ptab(m, s))) return rc;
+        if (rebuilt) { m->wgen++; HIP_TRY(hipStreamSynchronize(s)); }
+        if (m->seen_wgen != m->wgen) {                  // (a model that shares these buffers may have regrown the tables)
+            if (m->seen_wgen) { for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec); m->graphs.clear(); m->graph_seen.clear(); }
+            m->seen_wgen = m->wgen;
+        }
+    }
     m->lastN = N;
     m->lastT = cocr_out_len(W, m->hp.subsampling_factor);
     auto run_on = [&](const void *in, float *out) -> int {
@@ -1574,6 +1635,7 @@ extern "C" int cocr_decoder_adamw(cocr_model *m, const float *grad_weight, const
                                   float weight_decay, void *stream) {
     if (!m || !grad_weight || !grad_bias) return fail(COCR_EINVAL, "null argument");
     if (m->dtype < 0 || !m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (m->owner) return fail(COCR_ESTATE, "this model shares another model's weights: step the owner");
     if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f) || !(weight_decay >= 0.f))
         return fail(COCR_EINVAL, "invalid AdamW hyper-parameters");            // torch.optim.AdamW's own checks
     HIP_TRY(hipSetDevice(m->device));

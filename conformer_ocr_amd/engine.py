@@ -73,6 +73,12 @@ class HipRecognizer:
         _lib.check(self.lib.cocr_finalize(self._h, DTYPES[self.compute_dtype]))
         self.ready = True
 
+    def share_weights(self, owner: 'HipRecognizer') -> None:
+        """This packed copy reads `owner`'s weights and tables instead of its own (include/cocr.h: cocr_share_weights); keeps `owner` alive."""
+        _lib.check(self.lib.cocr_share_weights(self._h, owner._h))
+        self._weights_owner = owner
+        self.ready = True
+
     def finalize_empty(self) -> None:
         _lib.check(self.lib.cocr_finalize_empty(self._h, DTYPES[self.compute_dtype]))
         self.ready = True

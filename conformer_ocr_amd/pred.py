@@ -161,7 +161,8 @@ class PytorchRecognitionModel(nn.Module):
 
     def engine_pool(self, n: int, device: Optional[torch.device] = None) -> List[HipRecognizer]:
         """`n` packed copies of the device model for callers that keep several batches in flight, one per stream
-        (conformer_ocr_amd/evaluate.py `recognize(..., streams=n)`): each has its own workspace and captured launch sequences; the
+        (conformer_ocr_amd/evaluate.py `recognize(..., streams=n)`): each has its own workspace and captured launch sequences and reads the
+        first engine's weights (`cocr_share_weights`); the
         row-chain kernels run their throughput form (96-row blocks: every weight byte streamed once per block -- with several batches
         in flight the chip is full anyway).  Rebuilt when the parameters change, like `engine()`."""
         eng0 = self.engine(device)
@@ -169,8 +170,7 @@ class PytorchRecognitionModel(nn.Module):
             self._pool, self._pool_sig = [], self._engine_sig
         while len(self._pool) < n:
             eng = HipRecognizer(self.hparams_record, eng0.device, self.compute_dtype)
-            eng.load_state({k: v for k, v in self.nn.state_dict().items()}, strict=True)
-            eng.finalize()
+            eng.share_weights(eng0)        # one set of weights and tables for all copies (they stay in the Infinity Cache; include/cocr.h)
             eng.set_chain_rows(0)
             eng.set_graph(True)
             self._pool.append(eng)

@@ -96,6 +96,14 @@ int cocr_blob_import(cocr_model *m, const void *src_device, size_t bytes, void *
 /* calc_length (convolution.py:240-247) with k=3, s=2, p=1 repeated log2(subsampling_factor) times. */
 int32_t cocr_out_len(int32_t in_len, int32_t subsampling_factor);
 
+/* Several packed copies of ONE model (one per stream of a caller that keeps several batches in flight) need one set of weights: after
+ * this call `m` -- same hyper-parameters, same device -- reads `owner`'s packed weights, fragment-major copies and positional tables
+ * and keeps only a workspace and captured launch sequences of its own.  (Four private copies of the cfg2 model are 4 x ~100 MB, more than
+ * the 256 MB Infinity Cache: every forward then streamed its weights from HBM, cycling four copies on one stream ran 30 % slower than one.)
+ * `owner` must outlive `m` and must not itself share; weights are changed through the owner (set_tensor + finalize, blob import, the
+ * training entry points), `m` sees them at its next forward; finalizing `m` gives it weights of its own again. */
+int cocr_share_weights(cocr_model *m, cocr_model *owner);
+
 /* Host-side collation of a line batch: what kraken's `collate_sequences` does for the reference's loaders (cli/test.py:186-189, the
  * `DataLoader(..., collate_fn=collate_sequences)`): N lines of H rows each, line i `widths[i]` elements wide and C-contiguous, are
  * copied left-aligned into the (N,H,W) batch `dst` and the rest of every row is zeroed.  Plain host memory on both sides (dst is
