@@ -14,7 +14,10 @@ line batch resident in HBM -> conformer encoder (bf16 operands) -> decoder -> CT
       batches of <= `--batch` lines padded to their bucket's width; a step is the next batch of that queue.
 
 With N > 1 every rank owns one GPU, receives the packed weights by one RCCL broadcast and processes its own independent
-batches (no data-path collective): weak scaling.  Rank 0 prints ONE JSON line:
+batches (no data-path collective): weak scaling.  Launched either by `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` (RANK set by the launcher) or plainly as `python bench.py --gpus N ...`: without RANK in the environment this
+process starts the N rank processes itself (`launch_ranks`, before anything has touched the GPU) and forwards rank 0's line.
+Rank 0 prints ONE JSON line:
 
   value                 whole-job lines/s, `--streams` (4) batches in flight per GPU, inputs resident in HBM
   value_streams1        the same loop with ONE batch in flight (what a single caller thread without its own streams sees; 48-row workgroups)
@@ -33,12 +36,87 @@ import time
 # One hardware queue per batch in flight: the HIP runtime multiplexes its streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues,
 # and two of this bench's streams sharing a queue serialise "independent" batches (measured: 4 streams on the default 4 queues --
 # one is taken by the null stream -- 30.2k lines/s, on 8 queues 38.0k; 3 streams on 4 queues 36.6k).  Read at runtime start-up.
+_HWQ_PRESET = os.environ.get('GPU_MAX_HW_QUEUES')
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def launch_ranks(n, argv, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher around it: THIS process never touches the GPU (nothing before this point has
+    called HIP; `torch.cuda.device_count()` does not initialise it on this image) and starts N fresh rank processes of this same
+    script -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, exactly what
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` would give them.  Rank 0's stdout (the ONE JSON line) is
+    forwarded to this process's stdout, every rank's stderr is inherited.  Returns the exit code: 0 only if every rank returned 0 and
+    rank 0 printed a line; the first failing rank's code otherwise (the other ranks are terminated by PID).  No exec, no re-exec."""
+    import socket
+    import subprocess
+    if '--dry-run' not in argv:
+        import torch
+        seen = torch.cuda.device_count()
+        if seen < n:
+            sys.stderr.write(f'bench.py: --gpus {n} but only {seen} GPU(s) are visible\n')
+            return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != '--spawn'], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+    t_end = None if timeout_s is None else time.time() + timeout_s
+    rc, live = 0, set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0:
+                    sys.stderr.write(f'bench.py: rank {r} exited with code {c}\n')
+                    rc = c if c > 0 else 1
+        if t_end is not None and time.time() > t_end:
+            sys.stderr.write(f'bench.py: ranks {sorted(live)} still running after {timeout_s} s\n')
+            rc = 124
+        if live and rc == 0:
+            time.sleep(0.05)
+    for r in live:                                  # a rank failed: the others would wait for it at the next barrier
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    out = procs[0].stdout.read().decode('utf-8', 'replace') if procs[0].stdout else ''
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f'bench.py: rank 0 printed {len(lines)} lines, expected one\n')
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[0] + '\n')
+        sys.stdout.flush()
+    return rc
+
+
+def _launcher_args(argv):
+    """(gpus, spawn) from the command line without importing anything heavy."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--spawn', action='store_true')
+    a, _ = ap.parse_known_args(argv)
+    return a.gpus, a.spawn
+
+
+if __name__ == '__main__' and 'RANK' not in os.environ:
+    _n, _spawn = _launcher_args(sys.argv[1:])
+    if _n > 1 or _spawn:
+        sys.exit(launch_ranks(_n, sys.argv[1:]))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from conformer_ocr_amd import synth  # noqa: E402
@@ -193,6 +271,31 @@ def strings_of(records):
     return [[int(r[0]) for r in line] for line in records]
 
 
+def dry_run(args, json_fd):
+    """The launcher's rehearsal (tests/test_bench_launcher.py): every rank joins a gloo group, the ranks count themselves by an
+    all-reduce of ones, rank 0 prints one line that says it measured nothing."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if rank == args.dry_run_fail_rank:
+        sys.stderr.write(f'bench.py: dry-run rank {rank} fails on request\n')
+        sys.exit(3)
+    if world != args.gpus:
+        sys.exit(2)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    dist.barrier()
+    if rank == 0:
+        os.write(json_fd, (json.dumps({'metric': METRIC, 'value': None, 'unit': 'lines/s', 'n_gpus': world, 'dry_run': True,
+                                       'config': {'ranks_seen': int(ones.item()), 'backend': 'gloo'}}) + '\n').encode())
+    else:
+        print(f'rank {rank}: this text must not reach the launcher\'s stdout', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -211,11 +314,16 @@ def main():
     ap.add_argument('--queue-depth', type=int, default=2, help='steps queued per stream before the host waits for the oldest (1: a stream\'s next step is launched when its previous one has been collected)')
     ap.add_argument('--private-weights', action='store_true', help='every packed model copy holds its own weights (the form before cocr_share_weights)')
     ap.add_argument('--streams', type=int, default=4, help='independent batches in flight (one packed model + HIP stream each)')
+    ap.add_argument('--spawn', action='store_true', help='start the rank process(es) as fresh children of this process even for --gpus 1 (the path --gpus N > 1 always takes when no launcher set RANK)')
+    ap.add_argument('--dry-run', action='store_true', help='launcher rehearsal without a GPU: gloo rendezvous, barrier, all-reduce, a line with value null')
+    ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help='(dry run) this rank exits with code 3 before the rendezvous')
     args = ap.parse_args()
-    # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL at communicator creation) go to stderr
+    # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL / gloo at communicator creation) go to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.dry_run:
+        return dry_run(args, json_fd)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -230,6 +338,11 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    ranks_seen = 1
+    if use_dist:                             # the ranks count themselves over RCCL: the line says how many took part
+        ones = torch.ones(1, device=torch.device('cuda', local_rank))
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -524,7 +637,10 @@ def main():
             'config': {'workload': workload, 'lines_per_step_per_gpu': round(lines_per_cycle / NB, 2), 'batches_in_queue': NB,
                        'gflop_per_line': round(gflop, 3), 'gflop_per_line_padded': round(padded / 1e9, 3),
                        'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast', 'streams_per_gpu': S, 'steps_queued_per_stream': args.queue_depth,
-                       'hipgraph_replay': bool(use_graph)},
+                       'hipgraph_replay': bool(use_graph), 'rccl_ranks_seen': ranks_seen if use_dist else None,
+                       'launched_by': 'bench.py launch_ranks' if os.environ.get('LOCAL_WORLD_SIZE') and 'TORCHELASTIC_RUN_ID' not in os.environ and use_dist
+                                      else ('torch.distributed.run' if use_dist else 'in-process'),
+                       'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'), 'gpu_max_hw_queues_preset_by_caller': _HWQ_PRESET is not None},
             'achieved_tflops_whole_path': round(value * gflop / 1e3, 2),
             'achieved_tflops_whole_path_padded': round(value * padded / 1e12, 2),
             'cer_vs_reference': cer['cer_vs_reference'] if cer else None, 'cer': cer,

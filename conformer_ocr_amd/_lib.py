@@ -55,6 +55,8 @@ SYMBOLS = {
     'cocr_train_end': (_I, [_P]),
     'cocr_train_set_matmul': (_I, [_P, _I]),
     'cocr_train_grad_buffer': (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    'cocr_train_param_buffer': (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    'cocr_train_layout': (_I, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     'cocr_get_tensor': (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
     'cocr_preproc_width': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'cocr_preproc_lines': (_I, [_P, _P, C.POINTER(C.c_int64), _I32P, _I32P, _I32P, _I, _I, _I, _I, _P, _I32P, _P]),

@@ -544,6 +544,7 @@ extern "C" int cocr_weight_blob(cocr_model *m, void **device_ptr, size_t *bytes)
 extern "C" int cocr_blob_export(cocr_model *m, void *dst_device, size_t bytes, void *stream) {
     if (!m || !dst_device) return fail(COCR_EINVAL, "null argument");
     if (!m->blob) return fail(COCR_ESTATE, "model not finalized");
+    if (m->owner) return fail(COCR_ESTATE, "this model shares another model's weights: address the owner");      // (its own `blob` is a view that the owner may have re-allocated)
     if (bytes != m->plan.total) return fail(COCR_EINVAL, "blob is %zu bytes, buffer %zu", m->plan.total, bytes);
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(dst_device, m->blob, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1051,7 +1052,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         return COCR_OK;
     };
     if constexpr (sizeof(T) == 2) {
-        if (rowchain_supported(D, ff, dh) && !m->no_chain && !(m->debug && m->ksz != 31)) {      // (debug taps exist for the depthwise-fused chain shapes)
+        if (rowchain_supported(D, ff, dh) && !m->no_chain) {      // (debug taps: the TAPS instantiation of every chain shape)
             // ---- row-local chains (rowchain.hip.h): 3 launches per block (attention core, chain A, chain B)
             const unsigned char *CW = m->packed;                 // chain weights: fragment-major copies
             auto CWT = [&](size_t off) { return (const bf16_t *)(CW + off); };
@@ -1282,7 +1283,24 @@ static int forward_entry(cocr_model *m, const void *lines, int line_dtype, int N
             root->wgen++;
         }
     }
-    int rc = cocr_reserve(m, N, W);
+    int rc;
+    if (m->owner && (m->owner->dtype != m->dtype || m->owner->plan.total != m->plan.total)) {
+        // the owner was finalized again in another compute dtype since cocr_share_weights: this model's layout, plan, workspace and
+        // captured launches describe the old blob -- re-derived here, before anything is sized or launched from them
+        cocr_model *o = m->owner;
+        if (o->dtype < 0 || !o->blob) return fail(COCR_ESTATE, "the model whose weights this one shares is not finalized");
+        HIP_TRY(hipDeviceSynchronize());
+        if ((rc = set_engine_dims(m, o->dtype))) return rc;
+        for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear(); m->graph_seen.clear();
+        free_workspace(m);
+        m->plan = make_plan(m, o->dtype);
+        m->dtype = o->dtype;
+        m->blob = o->blob;
+        m->amax_logits = nullptr;
+        m->seen_wgen = 0;
+    }
+    rc = cocr_reserve(m, N, W);
     if (rc) return rc;
     if (in_lens && out_lens)
         for (int i = 0; i < N; ++i) out_lens[i] = cocr_out_len(in_lens[i], m->hp.subsampling_factor);

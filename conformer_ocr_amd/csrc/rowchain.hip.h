@@ -736,8 +736,8 @@ static inline hipError_t launch_rowchain(hipStream_t s, const ChainArgs &a, bool
     }
     if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_rowchain_cfg<D, 0, ST_FFN, ST_QKV, -1, -1, true>(s, a, taps, rows_hint);
     if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_GLU, -1, -1, true>(s, a, taps, rows_hint);
-    // (without the depthwise prologue: COCR_NO_DW_FUSE / conv kernels other than 31, A/B runs -- no debug instantiation)
-    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV, false>(s, a, taps, rows_hint);
-    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_FFN, -1, -1, false>(s, a, taps, rows_hint);
+    // (without the depthwise prologue: conv kernels other than 31 -- the stand-alone depthwise kernel runs before the launch --, COCR_NO_DW_FUSE A/B runs)
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV, true>(s, a, taps, rows_hint);
+    if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_FFN, -1, -1, true>(s, a, taps, rows_hint);
     return hipErrorInvalidValue;
 }

@@ -103,6 +103,29 @@ extern "C" int cocr_train_grad_buffer(cocr_model *m, void **device_ptr, size_t *
     return COCR_OK;
 }
 
+// the flat device VALUE vector in the same layout: parameters [0, n_params), then buffers (BatchNorm running statistics) up to n_total.
+// A caller that keeps the parameters elsewhere (torch: `net.nn.parameters()`, updated by a torch optimizer) writes them here before
+// cocr_train_step and reads the running statistics back afterwards (device-to-device, stream-ordered).
+extern "C" int cocr_train_param_buffer(cocr_model *m, void **device_ptr, size_t *n_total, size_t *n_params) {
+    if (!m || !device_ptr || !n_total || !n_params) return fail(COCR_EINVAL, "null argument");
+    if (!m->train) return fail(COCR_ESTATE, "cocr_train_begin has not been called");
+    *device_ptr = m->train->P;
+    *n_total = m->train->ntotal;
+    *n_params = m->train->nparam;
+    return COCR_OK;
+}
+// where a reference state-dict name lives in those vectors: float offset and element count; *is_param = 0 for a buffer (no gradient)
+extern "C" int cocr_train_layout(cocr_model *m, const char *name, int64_t *offset, int64_t *n_elems, int *is_param) {
+    if (!m || !name || !offset || !n_elems || !is_param) return fail(COCR_EINVAL, "null argument");
+    if (!m->train) return fail(COCR_ESTATE, "cocr_train_begin has not been called");
+    auto it = m->train->idx.find(name);
+    if (it == m->train->idx.end()) return fail(COCR_EINVAL, "unknown tensor '%s'", name);
+    *offset = (int64_t)it->second.off;
+    *n_elems = (int64_t)it->second.n;
+    *is_param = it->second.param ? 1 : 0;
+    return COCR_OK;
+}
+
 extern "C" int cocr_train_end(cocr_model *m) {
     if (!m) return fail(COCR_EINVAL, "null argument");
     TrainState *t = m->train;

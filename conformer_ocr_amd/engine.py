@@ -3,6 +3,7 @@ memory and streams; every computation is a call through the C ABI."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -18,8 +19,12 @@ def _stream_ptr(device: torch.device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_LAST_WRITER: Dict[int, int] = {}          # logits buffer address -> sequence number of the last `forward` (of any engine) that wrote it
+
+
 class HipRecognizer:
     """One packed model on one GPU."""
+    _WRITE_SEQ = 0
 
     def __init__(self, hp: HParams, device: torch.device, compute_dtype: str = 'bf16'):
         if compute_dtype not in DTYPES:
@@ -156,18 +161,30 @@ class HipRecognizer:
             _lib.check(self.lib.cocr_forward(self._h, C.c_void_p(lines.data_ptr()), ldt, N, H, W,
                                              in_lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(logits.data_ptr()),
                                              out_lens.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(self.device)))
-        self._fresh_logits = (logits.data_ptr(), logits._version)      # the decoder epilogue's per-frame argmax belongs to these values
+        # The decoder epilogue's per-frame argmax belongs to THESE values: to this tensor object (not to its address: the caching
+        # allocator hands a freed address to the next same-sized tensor), at this version, and only while no other engine's forward
+        # has written the same buffer since (writes through the C ABI do not bump `_version`: `_LAST_WRITER` records them).
+        HipRecognizer._WRITE_SEQ += 1
+        if len(_LAST_WRITER) > 4096:
+            _LAST_WRITER.clear()
+        _LAST_WRITER[logits.data_ptr()] = HipRecognizer._WRITE_SEQ
+        self._fresh_logits = (weakref.ref(logits), logits._version, HipRecognizer._WRITE_SEQ)
         return logits, out_lens
+
+    def _argmax_is_fresh(self, logits: torch.Tensor) -> bool:
+        ref, ver, seq = getattr(self, '_fresh_logits', None) or (None, -1, -1)
+        return ref is not None and ref() is logits and logits._version == ver and _LAST_WRITER.get(logits.data_ptr()) == seq
 
     def _decode_async(self, fn, logits: torch.Tensor, out_lens, extra=()):
         """Enqueues the decode kernel on the current stream, its outputs in pinned host memory; returns a handle for `collect`
         (the pinned buffers + an event)."""
         if logits.device != self.device or logits.dtype != torch.float32:
             raise RuntimeError('logits must be float32 on the model device')
+        fresh = self._argmax_is_fresh(logits)
         logits = logits.contiguous()
         N, T, ncls = logits.shape
         lens = np.ascontiguousarray(np.asarray(out_lens, dtype=np.int32).reshape(-1))
-        if getattr(self, '_fresh_logits', None) != (logits.data_ptr(), logits._version):
+        if not fresh:
             _lib.check(self.lib.cocr_forget_argmax(self._h))          # other logits, or edited in place since the forward: decode from the values
         with torch.cuda.device(self.device):
             # The decode kernels write their (sparse) label records STRAIGHT into pinned host memory (device-visible): no

@@ -123,23 +123,46 @@ class PytorchRecognitionModel(nn.Module):
         return out
 
     def invalidate_engine(self) -> None:
-        """Forces a re-pack of the device model at the next call (after replacing a parameter's `.data` by hand: in-place writes,
-        `load_state_dict` and `.to()` are noticed without this)."""
+        """Forces a re-pack of the device model at the next call.  Not needed after any of: in-place writes, `load_state_dict`
+        (also with `assign=True`), `.to()`, `p.data = new`, replacing a parameter, a buffer or a whole sub-module
+        (`net.nn.decoder = nn.Linear(...)`) -- `_signature` sees all of these."""
         self._sig_tensors = None
         self._engine_sig = None
 
     def _signature(self, device: torch.device):
-        """Identity of the weights the packed device model was built from: storage addresses (taken once per parameter-tree
-        change) and the sum of the tensors' in-place version counters (478 attribute reads for the 12-block model: ~40 us per
-        call; rebuilding `state_dict()` here cost 1.5 ms, more than a whole 32-line forward)."""
-        if self._sig_tensors is None:
-            ts = [*self.nn.parameters(), *self.nn.buffers()]
-            self._sig_tensors = (ts, tuple(t.data_ptr() for t in ts))
-        ts, ptrs = self._sig_tensors
-        ver = 0
+        """Identity of the weights the packed device model was built from, re-read on EVERY call:
+        * which objects hang in the module tree: ids of every module's children, parameters and buffers (a replaced sub-module,
+          `load_state_dict(assign=True)`, `del` / re-register) -- read from the modules' own dicts, not through `state_dict()`
+          or `parameters()` (1.5 ms / 0.6 ms per call for the 12-block model);
+        * where their values live: `data_ptr()` of every tensor (`p.data = new`, `.to()`);
+        * whether they were written in place: the sum of the version counters.
+        About 0.15 ms for 478 tensors in 539 modules; `forward` runs it AFTER it has enqueued the launch (the GPU is busy for
+        0.8 ms or more) and repeats the call in the rare case that the answer is "changed"."""
+        ids = None
+        if self._sig_tensors is not None:
+            ids = [id(v) for d in self._sig_tensors[1] for v in d.values()]
+        if ids is None or ids != self._sig_tensors[2]:
+            # first call, or the tree changed.  The cache keeps the modules and tensors it describes alive, so an id in `ids`
+            # cannot have been handed to a new object in the meantime; the generation counts the rebuilds.
+            mods = list(self.nn.modules())
+            dicts = [d for m in mods for d in (m._modules, m._parameters, m._buffers)]
+            self._sig_tensors = ([*self.nn.parameters(), *self.nn.buffers()], dicts, [id(v) for d in dicts for v in d.values()], mods)
+            self._sig_gen = getattr(self, '_sig_gen', 0) + 1
+        ts = self._sig_tensors[0]
+        ver, ptrs = 0, []
         for t in ts:
             ver += t._version
-        return (str(device), self.compute_dtype, ptrs, ver)
+            ptrs.append(t.data_ptr())
+        return (str(device), self.compute_dtype, self._sig_gen, tuple(ptrs), ver)
+
+    def _pack(self, device: torch.device, sig) -> HipRecognizer:
+        eng = HipRecognizer(self.hparams_record, device, self.compute_dtype)
+        eng.load_state({k: v for k, v in self.nn.state_dict().items()}, strict=True)
+        eng.finalize()
+        eng.set_chain_rows(self.chain_rows)
+        eng.set_graph(True)        # hipGraph replay of the launch sequence, staged for the fresh tensors every call brings
+        self._engine, self._engine_sig = eng, sig
+        return eng
 
     def engine(self, device: Optional[torch.device] = None) -> HipRecognizer:
         """The packed device model, (re)built when the parameters or the device changed."""
@@ -151,12 +174,7 @@ class PytorchRecognitionModel(nn.Module):
                                'there is no CPU fallback')
         sig = self._signature(device)
         if self._engine is None or sig != self._engine_sig:
-            eng = HipRecognizer(self.hparams_record, device, self.compute_dtype)
-            eng.load_state({k: v for k, v in self.nn.state_dict().items()}, strict=True)
-            eng.finalize()
-            eng.set_chain_rows(self.chain_rows)
-            eng.set_graph(True)        # hipGraph replay of the launch sequence, staged for the fresh tensors every call brings
-            self._engine, self._engine_sig = eng, sig
+            self._pack(device, sig)
         return self._engine
 
     def engine_pool(self, n: int, device: Optional[torch.device] = None) -> List[HipRecognizer]:
@@ -165,6 +183,8 @@ class PytorchRecognitionModel(nn.Module):
         first engine's weights (`cocr_share_weights`); the
         row-chain kernels run their throughput form (96-row blocks: every weight byte streamed once per block -- with several batches
         in flight the chip is full anyway).  Rebuilt when the parameters change, like `engine()`."""
+        from . import hw_queues_note
+        hw_queues_note(n)
         eng0 = self.engine(device)
         if getattr(self, '_pool_sig', None) != self._engine_sig:
             self._pool, self._pool_sig = [], self._engine_sig
@@ -203,9 +223,19 @@ class PytorchRecognitionModel(nn.Module):
             raise TypeError('lens is required (the reference raises in calc_length for lens=None)')
         if line.dim() != 4 or line.shape[1] != 1:
             raise ValueError(f'expected a (N,1,H,W) line batch, got {tuple(line.shape)}')
-        eng = self.engine(line.device if line.is_cuda else None)
-        with torch.no_grad():
-            probits, out_lens = eng.forward(line.squeeze(1), torch.as_tensor(lens).cpu().numpy())
+        lens_np = torch.as_tensor(lens).cpu().numpy()
+        eng = self._engine
+        if eng is None or not line.is_cuda or line.device != eng.device:
+            eng = self.engine(line.device if line.is_cuda else None)
+            probits, out_lens = eng.forward(line.squeeze(1), lens_np)
+        else:
+            # launch first, look at the parameters while the GPU works (`_signature`): a host-side check of 478 tensors in front of
+            # every launch was 10 % of a 32-line call
+            probits, out_lens = eng.forward(line.squeeze(1), lens_np)
+            sig = self._signature(eng.device)
+            if sig != self._engine_sig:                    # the weights changed since the model was packed: pack again, run again
+                eng = self._pack(eng.device, sig)
+                probits, out_lens = eng.forward(line.squeeze(1), lens_np)
         return probits, torch.from_numpy(out_lens)
 
     def transform_lines(self, crops, pad: int = 16, bucket_edge: int = 0, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -275,6 +305,17 @@ class PytorchRecognitionModel(nn.Module):
         if with_grad:
             out['grad_probits'] = grad
         return out
+
+    def training_step(self, batch: Dict, batch_idx: int = 0) -> torch.Tensor:
+        """The reference's `RecognitionModel.training_step` (model.py:147-152): train-mode forward (BatchNorm batch statistics, dropout
+        with the constructor's probabilities), summed CTC loss -- returned as a DIFFERENTIABLE 0-dim device tensor: `loss.backward()`
+        leaves `.grad` on every parameter of `self.nn` that requires grad, and any torch optimizer / Lightning loop drives the step
+        (model.py:283-289).  Forward and backward run in libcocr_hip.so (conformer_ocr_amd/autograd.py); fp32, or bf16-rounded
+        matmul operands with `self.matmul_precision = 'medium'` (the reference's cli/train.py:252)."""
+        if not any(p.requires_grad for p in self.nn.parameters()):
+            raise RuntimeError('no parameter of net.nn requires grad: call net.nn.requires_grad_(True) (the holders are created frozen for inference)')
+        from .autograd import training_step
+        return training_step(self, batch)
 
     def predict_labels(self, line: torch.tensor, lens: torch.Tensor = None) -> List[List[Tuple[int, int, int, float]]]:
         """

@@ -237,6 +237,12 @@ int cocr_train_end(cocr_model *m);
 int cocr_train_set_matmul(cocr_model *m, int bf16_operands);
 /* The flat device gradient vector (float32, all parameters): a data-parallel job all-reduces it between cocr_train_step and cocr_train_adamw. */
 int cocr_train_grad_buffer(cocr_model *m, void **device_ptr, size_t *n_floats);
+/* The flat device VALUE vector in the same layout (parameters [0, *n_params), then the BatchNorm running statistics up to *n_total) and
+ * the place of a reference state-dict name in both vectors.  This is what puts the step behind torch autograd (reference
+ * model.py:129-152: `loss.backward()`, then any torch optimizer, model.py:283-289): the host copies `net.nn.parameters()` in, runs
+ * cocr_train_step, hands slices of the gradient vector to autograd and copies the running statistics out -- conformer_ocr_amd/autograd.py. */
+int cocr_train_param_buffer(cocr_model *m, void **device_ptr, size_t *n_total, size_t *n_params);
+int cocr_train_layout(cocr_model *m, const char *name, int64_t *offset, int64_t *n_elems, int *is_param);
 
 #ifdef __cplusplus
 }

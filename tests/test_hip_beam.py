@@ -92,3 +92,26 @@ def test_beam_pruned_equals_exhaustive(C, T, beam, scale, monkeypatch):
     monkeypatch.setenv('COCR_BEAM_REF', '1')
     ref = HipRecognizer(hp, torch.device('cuda', 0), 'fp32').ctc_beam(x, lens, beam)
     assert fast == ref
+
+
+def test_metric_model_forward_then_beam16_against_the_oracle(text_case):
+    """BASELINE configs[4] composed: the metric's model (cfg2_text: D=256, 12 blocks) on 96x1200 lines -> HIP logits (T = 300,
+    128 classes) -> cocr_ctc_beam(beam 16), against oracle/ctc_ref.py::beam_decoder run on the SAME logits: labels, start and end
+    frames exact, scores within 1e-4 relative.  fp32 logits of lines 0-3 (the latency-bound small batch) and bf16 logits of all 32
+    lines; and on these peaked lines the beam's label string is the reference's greedy string.  (Semantics of the beam search are
+    the build's own restatement of kraken's algorithm: kraken is absent, the reference never calls it -- parity unpinned.)"""
+    from tests.hip_util import make_engine
+    tc = text_case('cfg2_text')
+    image, lens, idx = tc.batch(0)
+    for dtype, n in (('fp32', 4), ('bf16', tc.n)):
+        eng = make_engine(tc.hp, tc.state, dtype)
+        x = torch.from_numpy(image[:n, 0]).cuda()
+        logits, out_lens = eng.forward(x, lens[:n])
+        assert logits.shape == (n, 300, 128)
+        got = eng.ctc_beam(logits, out_lens, 16)
+        host = logits.cpu().numpy()
+        for k in range(n):
+            want = ref_beam(host[k, :int(out_lens[k])].T, 16)
+            assert [r[:3] for r in got[k]] == [r[:3] for r in want], (dtype, k)
+            np.testing.assert_allclose([r[3] for r in got[k]], [r[3] for r in want], rtol=1e-4)
+            assert [r[0] for r in got[k]] == tc.ref_strings[idx[k]], (dtype, k)

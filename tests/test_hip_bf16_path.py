@@ -55,8 +55,8 @@ def _ulp_ok(got, ref):
     return np.abs(got - ref) <= np.abs(ref) * 2.0 ** -7 + 5e-3
 
 
-@pytest.mark.parametrize('n,w', [(3, 232), (17, 1200)])
-def test_chain_kernel_stages_in_isolation_against_bf16_oracle(n, w):
+@pytest.mark.parametrize('n,w,ksz', [(3, 232, 31), (17, 1200, 31), (3, 232, 15), (17, 1200, 7)])
+def test_chain_kernel_stages_in_isolation_against_bf16_oracle(n, w, ksz):
     """Two blocks of the metric's model on ragged lines; (3, 232) runs the 32-row workgroups, (17, 1200) = 5100 rows the 96-row
     form.  The taps come from the TAPS instantiation of the chain kernels themselves.  Every stage is checked IN ISOLATION: the
     bf16-operand oracle recomputes the stage from the HIP path's own input to it (the previous tap), so the only differences
@@ -64,7 +64,9 @@ def test_chain_kernel_stages_in_isolation_against_bf16_oracle(n, w):
     fp32 stream taps within 6e-3 absolute, bf16-stored operands within one bf16 rounding step.  (Chained through all stages
     the same comparison reaches 2e-2 after two blocks: each flipped rounding is re-amplified by the following LayerNorms.)"""
     from oracle.conformer_ref import Oracle
-    hp = synth.hparams('cfg2', num_encoder_layers=2)
+    # conv_kernel_size 15 / 7: the stand-alone depthwise kernel + the chain shapes WITHOUT the depthwise prologue -- what those models
+    # run in production; their taps, too, come from the chain kernels (cocr_api.hip no longer leaves the chain path in debug mode)
+    hp = synth.hparams('cfg2', num_encoder_layers=2, conv_kernel_size=ksz)
     state = synth.make_state_dict(hp, seed=31, decoder_gain=1.0, style='text')
     widths = [max(40, w - 37 * i) for i in range(n)]
     image, lens = synth.make_lines(n, hp.height, w, seed=77, widths=widths)
@@ -123,7 +125,7 @@ def test_chain_kernel_stages_in_isolation_against_bf16_oracle(n, w):
     lg32, _ = _oracle_taps(hp, state, image, lens, False)
     worst['chained logits vs bf16 oracle'] = float(np.abs(logits - lg16).max())
     worst['chained logits vs fp32 oracle'] = float(np.abs(logits - lg32).max())
-    _log(f'chain_stages_n{n}_w{w}', worst)
+    _log(f'chain_stages_n{n}_w{w}_k{ksz}', worst)
     assert not bad, bad
     assert worst['chained logits vs bf16 oracle'] <= 0.05 and worst['chained logits vs fp32 oracle'] <= 0.15
 
@@ -192,7 +194,8 @@ def test_text_fixture_labels_and_strings(text_case, name, dtype):
     if dtype == 'fp32':
         assert dev <= 1e-3 and mism_all == 0
     else:
-        assert dev <= 0.5
+        assert dev <= 0.35           # measured 0.207 - 0.227 on logits of +-22 .. 28
+        assert mism_all <= 3         # measured 0 / 0 / 1: the frames under the margin filter agree as well
 
 
 def test_cfg2_text_logits_against_bf16_oracle(text_case):

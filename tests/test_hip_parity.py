@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the golden vectors made by the reference and
 against the CPU oracle.  Tolerances: fp32 mode 1e-3 abs on logits (north_star); bf16 mode on these RANDOM-weight
 fixtures (flat logits: most top-2 margins are a few bf16 roundings wide): a bounded logit deviation and greedy labels
-identical on every frame whose reference top-2 margin exceeds the CONSTANT BF16_MARGIN = 2 x the deviation bound.
+identical on every frame whose reference top-2 margin exceeds the CONSTANT BF16_MARGIN (0.7); a floor on the share of frames that filter leaves and a cap on label differences over all frames.
 String identity / CER of the bf16 mode is asserted on the peaked "text" fixtures in tests/test_hip_bf16_path.py."""
 import json
 import os
@@ -15,8 +15,21 @@ from tests.hip_util import hip_tap, make_engine, oracle_taps, run_hip
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
-BF16_DEV = 0.35          # bf16 operands, fp32 accumulate + fp32 residual stream, logits of magnitude ~20 (decoder gain 8)
-BF16_MARGIN = 2 * BF16_DEV
+BF16_DEV = 0.30          # bf16 operands, fp32 accumulate + fp32 residual stream, logits of magnitude ~20 (decoder gain 8)
+BF16_MARGIN = 0.7        # constant label filter of the random-weight fixtures
+# Per fixture (measured on MI355X, gpurun_out/parity.jsonl of round 2): logit deviation bound = 1.3 x measured; the share of frames the
+# margin filter leaves to the label comparison (a floor: the comparison must not become vacuous) and a cap on label differences over ALL
+# frames (flat random-weight logits: most margins are a few bf16 roundings wide).  The reference's default model (cfg1, D = 144, zero-
+# padded layout) and the wide model (cfg4) sit above the common 0.30.
+BF16_CASES = {
+    #               dev bound, measured dev, min checked share, max label differences over all frames
+    'tiny':        (0.29, 0.218, 0.70, 2),
+    'tiny2':       (0.17, 0.127, 0.60, 4),
+    'cfg1':        (0.40, 0.303, 0.40, 110),
+    'cfg2':        (0.30, 0.237, 0.012, 260),
+    'cfg2_ragged': (0.30, 0.244, 0.20, 110),
+    'cfg4':        (0.38, 0.288, 0.24, 80),
+}
 LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
 
 
@@ -70,8 +83,10 @@ def _check_case(case, name, dtype, n=None):
     else:
         sel = margins > BF16_MARGIN
     mism = int((labels[sel] != g['labels'][:n][sel]).sum())
+    mism_all = int((labels != g['labels'][:n]).sum())
     _log(f'{name}_{dtype}', {'max_abs_logit_dev': dev, 'frames': int(sel.size), 'frames_checked': int(sel.sum()), 'label_mismatch': mism,
-                             'label_mismatch_all_frames': int((labels != g['labels'][:n]).sum())})
+                             'label_mismatch_all_frames': mism_all})
+    _check_case.last = {'checked_share': float(sel.mean()), 'mism_all': mism_all}
     return dev, mism, eng, logits, out_lens
 
 
@@ -107,8 +122,11 @@ def test_fp32_cfg2_full_batch(case):
 @pytest.mark.parametrize('name', ['tiny', 'tiny2', 'cfg1', 'cfg2', 'cfg2_ragged', 'cfg4'])
 def test_bf16_labels_identical_outside_margin(case, name):
     dev, mism, *_ = _check_case(case, name, 'bf16')
+    bound, _measured, min_share, max_all = BF16_CASES[name]
     assert mism == 0
-    assert dev <= BF16_DEV      # (the reference itself under CPU bf16 autocast: ~0.05 on logits of 1/8 this gain)
+    assert dev <= bound      # (the reference itself under CPU bf16 autocast: ~0.05 on logits of 1/8 this gain)
+    assert _check_case.last['checked_share'] >= min_share, _check_case.last      # the filter leaves frames to compare
+    assert _check_case.last['mism_all'] <= max_all, _check_case.last            # and outside it the labels do not drift apart either
 
 
 def test_u8_ingest_equals_f32_ingest(case):

@@ -90,3 +90,30 @@ def test_weights_change_through_the_owner_only():
     assert np.array_equal(sharer.forward(x, lens)[0].cpu().numpy(), a)
     del owner                                            # (the sharer no longer depends on it)
     assert np.array_equal(sharer.forward(x, lens)[0].cpu().numpy(), a)
+
+
+def test_owner_finalized_again_in_another_compute_dtype():
+    """The header allows weight changes through the owner (set_tensor + finalize): also a finalize in the OTHER compute dtype.  The
+    sharer then follows -- layout, plan, workspace and captured launches re-derived at its next forward -- instead of running its bf16
+    kernels over an fp32 blob.  And a sharer hands out no blob copy (its view of the owner's buffer may be gone): the owner does."""
+    hp, state, owner, private, sharer = _engines('bf16')
+    img, lens = synth.make_lines(3, hp.height, 500, seed=12, widths=[500, 420, 77])
+    x = torch.from_numpy(img[:, 0]).cuda()
+    sharer.set_graph(True)
+    bf = [sharer.forward(x, lens)[0].cpu().numpy() for _ in range(3)][-1]
+    assert np.array_equal(bf, private.forward(x, lens)[0].cpu().numpy())
+    with pytest.raises(RuntimeError, match='owner'):
+        sharer.export_blob()
+    owner.compute_dtype = 'fp32'
+    owner.finalize()
+    p32 = HipRecognizer(hp, owner.device, 'fp32')
+    p32.load_state(state)
+    p32.finalize()
+    want = p32.forward(x, lens)[0].cpu().numpy()
+    for _ in range(3):                                   # plain, captured, replayed: all on the new blob
+        got = sharer.forward(x, lens)[0].cpu().numpy()
+        assert np.array_equal(got, want)
+    assert np.abs(got - bf).max() > 1e-4                 # (it is the fp32 result, not the old one)
+    owner.compute_dtype = 'bf16'
+    owner.finalize()
+    assert np.array_equal(sharer.forward(x, lens)[0].cpu().numpy(), bf)

@@ -226,3 +226,39 @@ def test_alignment_report_known_answers():
     assert conf == {('b', ''): 1, ('1', '7'): 1} and dels == 1 and subs == {'Digit': 1} and scripts == {'Latin': 2, 'Digit': 1}
     rep = render_report('m', 6, 3, 0.5, 0.0, *compute_confusions(list('kitten') + [''], list('sittin') + ['g']))
     assert '6\tCharacters' in rep and '3\tErrors' in rep and '50.00%\tCharacter Accuracy' in rep and '{ k } - { s }' in rep
+
+
+def test_signature_sees_every_kind_of_weight_change():
+    """pred.py `_signature` (CPU: no packed model is built): in-place writes, load_state_dict with and without assign=True, `p.data =`,
+    a replaced parameter, a replaced sub-module, two parameters swapped between modules -- each changes it; nothing changes it otherwise."""
+    hp = synth.hparams('tiny')
+    net = _net(hp)
+    dev = torch.device('cpu')
+    seen = [net._signature(dev)]
+
+    def changed():
+        s = net._signature(dev)
+        assert s == net._signature(dev)
+        assert all(s != t for t in seen), 'a weight change went unnoticed'
+        seen.append(s)
+
+    assert net._signature(dev) == seen[0]
+    with torch.no_grad():
+        net.nn.decoder.bias.add_(1.0)
+    changed()
+    net.nn.load_state_dict({k: v.clone() for k, v in net.nn.state_dict().items()})
+    changed()
+    net.nn.load_state_dict({k: v.clone() for k, v in net.nn.state_dict().items()}, assign=True)
+    changed()
+    net.nn.decoder.weight.data = torch.zeros_like(net.nn.decoder.weight)
+    changed()
+    net.nn.decoder = torch.nn.Linear(hp.encoder_dim, hp.num_classes)
+    changed()
+    a = net.nn.encoder.layers._modules['0'].sequential._modules['4']
+    b = net.nn.encoder.layers._modules['1'].sequential._modules['4']
+    a.weight, b.weight = b.weight, a.weight
+    changed()
+    a.weight = torch.nn.Parameter(torch.ones_like(a.weight), requires_grad=False)
+    changed()
+    net.float()
+    assert net._signature(dev) == net._signature(dev)
