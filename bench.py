@@ -104,6 +104,7 @@ def _launcher_args(argv):
     """(gpus, spawn) from the command line without importing anything heavy."""
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--prewarm-ms', type=float, default=500.0, help='untimed run of the same loop before the warm-up steps (clock ramp of an idle chip)')
     ap.add_argument('--spawn', action='store_true')
     a, _ = ap.parse_known_args(argv)
     return a.gpus, a.spawn
@@ -314,6 +315,7 @@ def main():
     ap.add_argument('--queue-depth', type=int, default=2, help='steps queued per stream before the host waits for the oldest (1: a stream\'s next step is launched when its previous one has been collected)')
     ap.add_argument('--private-weights', action='store_true', help='every packed model copy holds its own weights (the form before cocr_share_weights)')
     ap.add_argument('--streams', type=int, default=4, help='independent batches in flight (one packed model + HIP stream each)')
+    ap.add_argument('--prewarm-ms', type=float, default=500.0, help='untimed run of the same loop before the warm-up steps (clock ramp of an idle chip)')
     ap.add_argument('--spawn', action='store_true', help='start the rank process(es) as fresh children of this process even for --gpus 1 (the path --gpus N > 1 always takes when no launcher set RANK)')
     ap.add_argument('--dry-run', action='store_true', help='launcher rehearsal without a GPU: gloo rendezvous, barrier, all-reduce, a line with value null')
     ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help='(dry run) this rank exits with code 3 before the rendezvous')
@@ -447,6 +449,12 @@ def main():
                     lg, ol = engines[k].forward(batches[b]['x'], batches[b]['lens'], out=outs[k][b])
                     engines[k].collect(engines[k].ctc_greedy_async(lg, ol))
     torch.cuda.synchronize(dev)
+    # ... and the chip is brought to its steady state (clocks, caches, the runtime's launch pipeline) by `--prewarm-ms` of the same
+    # loop before the W warm-up steps: with --steps 20 the first rounds after an idle chip ran 10 % slower than the steady ones
+    # (DESIGN.md "The timed region's length"), which says nothing about the kernels
+    t_pw = time.perf_counter()
+    while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+        run_steps(4 * S, S)
 
     run_steps(args.warmup, S)
     fence()
@@ -637,7 +645,7 @@ def main():
             'config': {'workload': workload, 'lines_per_step_per_gpu': round(lines_per_cycle / NB, 2), 'batches_in_queue': NB,
                        'gflop_per_line': round(gflop, 3), 'gflop_per_line_padded': round(padded / 1e9, 3),
                        'parallelism': f'{world} independent rank(s), weights by one RCCL broadcast', 'streams_per_gpu': S, 'steps_queued_per_stream': args.queue_depth,
-                       'hipgraph_replay': bool(use_graph), 'rccl_ranks_seen': ranks_seen if use_dist else None,
+                       'hipgraph_replay': bool(use_graph), 'prewarm_ms': args.prewarm_ms, 'rccl_ranks_seen': ranks_seen if use_dist else None,
                        'launched_by': 'bench.py launch_ranks' if os.environ.get('LOCAL_WORLD_SIZE') and 'TORCHELASTIC_RUN_ID' not in os.environ and use_dist
                                       else ('torch.distributed.run' if use_dist else 'in-process'),
                        'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'), 'gpu_max_hw_queues_preset_by_caller': _HWQ_PRESET is not None},

@@ -26,7 +26,7 @@ BF16_CASES = {
     'tiny':        (0.29, 0.218, 0.70, 2),
     'tiny2':       (0.17, 0.127, 0.60, 4),
     'cfg1':        (0.40, 0.303, 0.40, 110),
-    'cfg2':        (0.30, 0.237, 0.012, 260),
+    'cfg2':        (0.30, 0.237, 0.09, 900),
     'cfg2_ragged': (0.30, 0.244, 0.20, 110),
     'cfg4':        (0.38, 0.288, 0.24, 80),
 }
