@@ -104,7 +104,6 @@ def _launcher_args(argv):
     """(gpus, spawn) from the command line without importing anything heavy."""
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--prewarm-ms', type=float, default=500.0, help='untimed run of the same loop before the warm-up steps (clock ramp of an idle chip)')
     ap.add_argument('--spawn', action='store_true')
     a, _ = ap.parse_known_args(argv)
     return a.gpus, a.spawn
@@ -194,7 +193,7 @@ def pmc_traffic(family, live_avg_ms, hp, rows, tag):
     import csv
     import glob
     name = profile_kernel_name(family, hp, rows)
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', f'*{tag}_pmc_traffic.csv')) if ('_cfg4' in os.path.basename(f)) == bool(tag))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', f'*{tag}_pmc_traffic.csv')) if ('_cfg' in os.path.basename(f)) == bool(tag))
     if name is None or not files:
         return None, None
     f = files[-1]
@@ -315,6 +314,7 @@ def main():
     ap.add_argument('--queue-depth', type=int, default=2, help='steps queued per stream before the host waits for the oldest (1: a stream\'s next step is launched when its previous one has been collected)')
     ap.add_argument('--private-weights', action='store_true', help='every packed model copy holds its own weights (the form before cocr_share_weights)')
     ap.add_argument('--streams', type=int, default=4, help='independent batches in flight (one packed model + HIP stream each)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the bounded cfg4 / cfg1 legs of the default line')
     ap.add_argument('--prewarm-ms', type=float, default=500.0, help='untimed run of the same loop before the warm-up steps (clock ramp of an idle chip)')
     ap.add_argument('--spawn', action='store_true', help='start the rank process(es) as fresh children of this process even for --gpus 1 (the path --gpus N > 1 always takes when no launcher set RANK)')
     ap.add_argument('--dry-run', action='store_true', help='launcher rehearsal without a GPU: gloo rendezvous, barrier, all-reduce, a line with value null')
@@ -600,7 +600,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]['share'])
         d = kernels[dom]
         rows = batches[pb]['n'] * eng.out_len(batches[pb]['w'])
-        traffic, tinfo = pmc_traffic(dom, d['avg_ms'], hp, rows, '_cfg4' if args.config == 'cfg4' else '')
+        traffic, tinfo = pmc_traffic(dom, d['avg_ms'], hp, rows, '' if args.config == 'cfg2' else '_' + args.config)
         roof = {'kernel': dom, 'bound': 'hbm' if d['bound'] == 'hbm' else 'mfma', 'achieved': d['achieved'], 'peak': d['peak'],
                 'unit': d['unit'], 'frac': d['frac'], 'traffic': traffic, 'traffic_profile': tinfo, 'avg_ms': d['avg_ms'], 'share_of_step': d['share'],
                 'algorithmic_per_launch': table[dom][1], 'event_pair_overhead_ms': round(ovh, 5),
@@ -630,6 +630,40 @@ def main():
                 roof['rows48'] = {'avg_ms': round(ms48, 5), 'achieved': round(ach, 3), 'frac': round(ach / d['peak'], 5),
                                   'cus_occupied': min(256, 2 * cus_occupied(dom, hp, rows))}
 
+    # ---- the other single-GPU workloads of BASELINE.json's `configs` (never `value`): configs[3]'s wide model on a mixed-width bucketed
+    # queue and the reference's default model (default_specs.py:48-61) on the metric's batch shape -- each a bounded run of THIS script
+    # in a fresh child process (its own model, its own prewarm), reduced to value / CER / the dominant kernel's roofline fraction
+    others = None
+    if rank == 0 and world == 1 and args.config == 'cfg2' and not args.no_extra_legs and not args.no_other_configs:
+        import subprocess
+        for e in engines:
+            e.set_graph(False)
+        torch.cuda.synchronize(dev)
+        others = {}
+        for cfg, extra_args in (('cfg4', ['--steps', '50', '--warmup', '5', '--lines', '320']), ('cfg1', ['--steps', '100', '--warmup', '5'])):
+            cmd = [sys.executable, os.path.abspath(__file__), '--config', cfg, '--gpus', '1', '--no-cpu-baseline', '--no-extra-legs', '--no-other-configs',
+                   '--profile-steps', '2', '--prewarm-ms', '200', '--dtype', args.dtype] + extra_args
+            t_c = time.perf_counter()
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
+                ln = [x for x in r.stdout.splitlines() if x.startswith('{')]
+                if r.returncode != 0 or not ln:
+                    others[cfg] = {'error': f'rc {r.returncode}: ' + r.stderr[-300:]}
+                    continue
+                j = json.loads(ln[-1])
+                rf = j.get('roofline') or {}
+                others[cfg] = {'value': j['value'], 'unit': 'lines/s', 'steps': j['steps'], 'ms_per_step': j['ms_per_step'], 'workload': j['config']['workload'],
+                               'lines_per_step': j['config']['lines_per_step_per_gpu'], 'streams_per_gpu': j['config']['streams_per_gpu'],
+                               'gflop_per_line': j['config']['gflop_per_line'], 'gflop_per_line_padded': j['config']['gflop_per_line_padded'],
+                               'achieved_tflops_whole_path_padded': j['achieved_tflops_whole_path_padded'],
+                               'cer_vs_reference': j['cer_vs_reference'], 'lines_identical_to_reference': (j.get('cer') or {}).get('lines_identical_to_reference'),
+                               'fixture_lines': (j.get('cer') or {}).get('lines'),
+                               'roofline': {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_ms', 'cus_occupied', 'frac_of_occupied_cus')},
+                               'wall_s': round(time.perf_counter() - t_c, 1)}
+            except subprocess.TimeoutExpired:
+                others[cfg] = {'error': 'no line within 150 s'}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(hp, state, max_w if args.config != 'cfg4' else 1400, sample_lines=min(32, args.batch) if args.config != 'cfg4' else 8)
@@ -653,6 +687,7 @@ def main():
             'achieved_tflops_whole_path_padded': round(value * padded / 1e12, 2),
             'cer_vs_reference': cer['cer_vs_reference'] if cer else None, 'cer': cer,
             **extra,
+            'other_configs': others,
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
             'labels_emitted_last_step': int(sum(len(r) for r in recs)),
         }
