@@ -149,6 +149,7 @@ def kernel_table(hp, n, w, dtype):
         'gemm_ffn_down': ('mfma', 2.0 * M * D * ff),
         'ffn_fused': ('mfma', 4.0 * M * D * ff),
         'chain_ffn_qkv': ('mfma', 4.0 * M * D * ff + 6.0 * M * D * D),
+        'chain_front_ffn_qkv': ('mfma', 2.0 * M * F * C * D + 4.0 * M * D * ff + 6.0 * M * D * D),
         'chain_attn_out_glu': ('mfma', 6.0 * M * D * D),
         'chain_pw2_ffn_ffn_qkv': ('mfma', 8.0 * M * D * ff + 8.0 * M * D * D),
         'chain_pw2_ffn': ('mfma', 4.0 * M * D * ff + 2.0 * M * D * D),
@@ -163,9 +164,16 @@ def kernel_table(hp, n, w, dtype):
     }
 
 
+def engine_dim(hp):
+    """Width the bf16 engine runs a model at (cocr_api.hip set_engine_dims): 128 <= encoder_dim < 256 as a zero-padded 256-wide model,
+    256 < encoder_dim < 512 as a 512-wide one."""
+    d = hp.encoder_dim
+    return 256 if 128 <= d <= 256 else 512 if 256 < d <= 512 else d
+
+
 def chain_block_rows(hp, rows):
     """Rows per workgroup of the row-chain kernels in the throughput form (rowchain.hip.h rowchain_pick_mt)."""
-    big = 96 if hp.encoder_dim == 256 else 64
+    big = 96 if engine_dim(hp) == 256 else 64
     return big if rows >= big * 50 else 32
 
 
@@ -178,9 +186,9 @@ def cus_occupied(family, hp, rows):
 
 def profile_kernel_name(family, hp, rows):
     """Substring of the kernel's name in the rocprofv3 summaries."""
-    chain = {'chain_pw2_ffn_ffn_qkv': '31, 0, 1, 1, 3', 'chain_attn_out_glu': '0, 0, 2, -1, -1', 'chain_ffn_qkv': '0, 1, 3, -1, -1', 'chain_pw2_ffn': '31, 0, 1, -1, -1'}
+    chain = {'chain_pw2_ffn_ffn_qkv': '31, 0, 1, 1, 3', 'chain_attn_out_glu': '0, 0, 2, -1, -1', 'chain_ffn_qkv': '0, 1, 3, -1, -1', 'chain_front_ffn_qkv': '0, 4, 1, 3, -1', 'chain_pw2_ffn': '31, 0, 1, -1, -1'}
     if family in chain:
-        return f'rowchain_kernel<{hp.encoder_dim}, {chain_block_rows(hp, rows) // 16}, {chain[family]}'
+        return f'rowchain_kernel<{engine_dim(hp)}, {chain_block_rows(hp, rows) // 16}, {chain[family]}'
     return {'ffn_fused': 'ffn_fused_kernel', 'attention': 'relpos_attention_kernel', 'dwconv': 'dwconv_bn_silu', 'frontend_conv12': 'frontend_conv12',
             'frontend_fused': 'frontend96_kernel'}.get(family)
 

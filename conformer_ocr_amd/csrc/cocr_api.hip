@@ -161,6 +161,7 @@ struct cocr_model {
     bool no_conv_mfma = false;   // COCR_NO_CONV_MFMA=1: the all-VALU fp32 frontend conv kernel also in bf16 mode (A/B)
     bool no_dw_fuse = false;     // COCR_NO_DW_FUSE=1: depthwise conv as its own launch (A/B)
     int chain_rows = 0;          // rows per workgroup of the row-chain kernels (cocr_set_chain_rows / COCR_CHAIN_ROWS); 0 = by the number of rows
+    bool no_front_chain = false; // COCR_NO_FRONT_CHAIN=1: the frontend's output linear as a split-K GEMM + reduction in front of the first chain launch (A/B)
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
@@ -173,9 +174,9 @@ struct cocr_model {
 };
 
 static const char *FAMILIES[] = {"frontend_fused", "frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
-                                 "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "chain_ffn_qkv", "chain_attn_out_glu", "chain_pw2_ffn_ffn_qkv", "chain_pw2_ffn", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
+                                 "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "chain_ffn_qkv", "chain_front_ffn_qkv", "chain_attn_out_glu", "chain_pw2_ffn_ffn_qkv", "chain_pw2_ffn", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
                                  "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam", "ctc_loss", "event_pair_overhead"};
-enum { FAM_FRONT96, FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_CH_FIRST, FAM_CH_A, FAM_CH_B, FAM_CH_LAST, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
+enum { FAM_FRONT96, FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_CH_FIRST, FAM_CH_FRONT, FAM_CH_A, FAM_CH_B, FAM_CH_LAST, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
        FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_LOSS, FAM_EMPTY, FAM_COUNT };
 
 static int out_len1(int l) { return l >= 1 ? (l - 1) / 2 + 1 : 0; }
@@ -216,6 +217,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_PAD"); m->no_pad = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CHAIN"); m->no_chain = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_NO_FRONT_CHAIN"); m->no_front_chain = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_ROWS"); m->chain_rows = e ? atoi(e) : 0; }
     { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
@@ -875,6 +877,7 @@ static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k,
     return hipGetLastError();
 }
 
+static bool uses_chain96(const cocr_model *m);
 static bool uses_frontend96(const cocr_model *m);
 static int ensure_ctc_scratch(cocr_model *m, size_t rows);
 
@@ -962,6 +965,8 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     const float ffr = m->hp.half_step_residual ? 0.5f : 1.0f;
     const float scale = 1.0f / sqrtf((float)m->rdh);    // (the model's d_head: a padded model's engine d_head is its 64-wide slot)
     const bool rowln = gemm_rowln_supported<T>(D);       // N == D products own whole rows: residual + LayerNorm in their epilogue
+    // bf16 row chains: the output linear (K = F C) is the first stage of the first chain launch
+    const bool front_in_chain = sizeof(T) == 2 && uses_chain96(m) && (F * C) % 256 == 0 && !m->no_front_chain;
     auto ln = [&](size_t g1, size_t b1, bool write_f32, long g2, long b2) -> int {
         ProfScope ps(m, s, FAM_LN);
         launch_layernorm<T>(s, x, M, D, F32(g1), F32(b1), write_f32 ? x : nullptr, g2 >= 0 ? F32((size_t)g2) : nullptr,
@@ -1011,6 +1016,9 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
 #endif
         constexpr int SPLITS = COCR_FO_SPLITS;
         const int Kf = F * C;
+        if (front_in_chain) {
+            // the first row-chain launch multiplies the frontend output by the output linear itself (rowchain.hip.h: FRONT stage)
+        } else {
         const bool splitk = rowln && (Kf % (SPLITS * (128 / (int)sizeof(T))) == 0) && D <= 256 &&
                             (size_t)SPLITS * M * D * 4 <= (size_t)N * T2 * F2 * C * sizeof(T);
         if (splitk) {
@@ -1023,8 +1031,9 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         } else if ((rc = gemm_to_stream(FAM_FOUT, zcur, Kf, P.wout, P.bout, 1.0f, false, P.layers[0].ffn[0].ln_g, P.layers[0].ffn[0].ln_b, -1, -1))) {
             return rc;
         }
+        }
     }
-    if ((rc = tap<float>(m, s, "front.y", x, (size_t)M * D))) return rc;
+    if (!front_in_chain && (rc = tap<float>(m, s, "front.y", x, (size_t)M * D))) return rc;
 
     if (m->vtN != N || m->vtT != Tn) {   // pad dims of q, k, v must read as zero for this shape
         HIP_TRY(hipMemsetAsync(q, 0, m->qkv_bytes, s));
@@ -1070,7 +1079,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 for (int i = 0; i < 4; ++i) tp[i] = m->tapbuf + (size_t)i * M * D;
                 tap_dw = reinterpret_cast<bf16_t *>(m->tapbuf + (size_t)4 * M * D);
             }
-            auto tapx = [&](int l, const char *what, const float *src) -> int { snprintf(nm, sizeof nm, "l%d.%s", l, what); return tap<float>(m, s, nm, src, (size_t)M * D); };
+            auto tapx = [&](int l, const char *what, const float *src) -> int { if (l < 0) snprintf(nm, sizeof nm, "%s", what); else snprintf(nm, sizeof nm, "l%d.%s", l, what); return tap<float>(m, s, nm, src, (size_t)M * D); };
             auto tapb = [&](int l, const char *what, const T *src, size_t n) -> int { snprintf(nm, sizeof nm, "l%d.%s", l, what); return tap<T>(m, s, nm, src, n); };
             auto tap_qkv = [&](int l) -> int {
                 if (!taps) return COCR_OK;
@@ -1092,7 +1101,17 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             auto st_qkv = [&](const LayerW &lw) {
                 ChainStage st{}; st.kind = ST_QKV; st.W = CWT(lw.wqkv); st.bias = F32(lw.bqkv); st.N = 3 * D;
                 st.q = (bf16_t *)q; st.k = (bf16_t *)k; st.v = (bf16_t *)v; return st; };
-            {   // first block's FFN + q/k/v projection on the frontend output
+            if (front_in_chain) {   // frontend output linear + first LayerNorm -> first block's FFN -> its q/k/v projection
+                ChainArgs a = base(); a.A0 = (const bf16_t *)zcur; a.nstages = 3; a.x_in_blocked = 0;
+                ChainStage f{}; f.kind = ST_FRONT; f.W = CWT(P.wout); f.bias = F32(P.bout); f.N = D; f.K = F * C; f.alpha = 1.0f;
+                f.g1 = F32(P.layers[0].ffn[0].ln_g); f.b1 = F32(P.layers[0].ffn[0].ln_b);
+                a.st[0] = f;
+                a.st[1] = st_ffn(P.layers[0].ffn[0], P.layers[0].a_ln_g, P.layers[0].a_ln_b, -1, -1); a.st[1].store_x = 1;
+                a.st[2] = st_qkv(P.layers[0]);
+                a.st[0].tap_pre = tp[1]; a.st[1].tap_pre = tp[0];
+                { ProfScope ps(m, s, FAM_CH_FRONT); GEMM_TRY(launch(a)); }
+                if (taps && ((rc = tapx(-1, "front.y", tp[1])) || (rc = tapx(0, "ffn1", tp[0])) || (rc = tap_qkv(0)))) return rc;
+            } else {   // first block's FFN + q/k/v projection on the frontend output
                 ChainArgs a = base(); a.A0 = (const bf16_t *)xn; a.nstages = 2; a.x_in_blocked = 0;
                 a.st[0] = st_ffn(P.layers[0].ffn[0], P.layers[0].a_ln_g, P.layers[0].a_ln_b, -1, -1); a.st[0].store_x = 1;
                 a.st[1] = st_qkv(P.layers[0]);
@@ -1232,6 +1251,7 @@ static int ensure_packed(cocr_model *m, hipStream_t s) {
             for (int i = 0; i < 2; ++i) { pack(w.ffn[i].w1, ff, D); pack(w.ffn[i].w2, D, ff, ffr); }
             pack(w.wqkv, 3 * D, D); pack(w.wo, D, D); pack(w.wpw1, 2 * D, D); pack(w.wpw2, D, D);
         }
+    if (uses_chain96(m) && (m->feats[m->snum - 1] * C) % 256 == 0) pack(m->plan.wout, D, m->feats[m->snum - 1] * C);      // the FRONT stage's matrix
     if (uses_frontend96(m)) {
         pack(m->plan.stages[0].pw_w, C, C);
         const size_t n0 = (size_t)(C / 16) * 64 * 4, n2 = (size_t)(C / 16) * 5 * 64 * 8;

@@ -3,7 +3,7 @@
 // Everything in a block except the attention core (needs all frames of a line) maps a row of the (M, D) activation to a row:
 // projections, feed-forward modules, residual adds, LayerNorms, and -- with a +-15 frame halo -- the depthwise conv.  A workgroup
 // that owns a block of rows therefore runs a whole sequence of them back to back:
-//     first chain (block 0):                 FFN 1 (+ residual + LayerNorm)  ->  q/k/v projection
+//     first chain (block 0):                 frontend output linear (K = F C, + LayerNorm)  ->  FFN 1 (+ residual + LayerNorm)  ->  q/k/v projection
 //     chain A (after the attention core):    out-proj + residual + LayerNorm  ->  pointwise conv 1 + GLU
 //     chain B (after the GLU):               depthwise conv + BatchNorm + SiLU  ->  pointwise conv 2 + residual + LayerNorm  ->  FFN 2
 //                                            (+ block-final LayerNorm + next block's LayerNorm)  ->  next block's FFN 1 (+ LayerNorm)
@@ -126,7 +126,25 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.dw_in + (size_t)mrow * D + h * 256 + (lane & 31) * 8), (lds_ptr_t)(hs + q2 * 1024), 16, 0, 0);
         }
     };
-    if constexpr (DWK == 0) {
+    // FRONT (first stage = the frontend's output linear, K = F C): its (BMC x 256)-deep operand slices go through the two hidden-image areas,
+    // double buffered, MT wave-instructions per wave and slice (4 panels x BMC / 8 row groups of 8 rows x 128 B)
+    constexpr bool FRONT0 = K0 == ST_FRONT;
+    static_assert(!FRONT0 || DWK == 0, "the output linear starts a launch");
+    static_assert(K1 != ST_FRONT && K2 != ST_FRONT && K3 != ST_FRONT, "FRONT is a first stage");
+    auto front_dma = [&](int ks) {
+        unsigned char *buf = hs + (ks & 1) * IMGH;
+        const int Kf = p.st[0].K;
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const int id = wave + 8 * u, pnl = id / (BMC / 8), rg = id - pnl * (BMC / 8), row = rg * 8 + lrow;
+            const T *src = p.A0 + (size_t)min(m0 + row, M - 1) * Kf + ks * 256 + pnl * 64 + ((cpos ^ (row & 7)) * 8);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(buf + pnl * PANEL + rg * 1024), 16, 0, 0);
+        }
+    };
+    static_assert(4 * (BMC / 8) == 8 * MT, "operand slice: MT wave-instructions per wave");
+    if constexpr (FRONT0) {
+        front_dma(0);
+    } else if constexpr (DWK == 0) {
         // ---- first operand tile -> LDS image: (D / 64) panels x BMC / 8 row groups of 8 rows, one wave-instruction each
         for (int id = wave; id < (D / 64) * (BMC / 8); id += 8) {
             const int pnl = id / (BMC / 8), rg = id - pnl * (BMC / 8), row = rg * 8 + lrow;
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     bf16x8 ring[16];
     auto fill = [&](const T *slice, int f) { ring[f] = *reinterpret_cast<const bf16x8 *>(slice + f * 512 + lane * 8); };
     {
-        const T *first = p.st[0].W + (size_t)wave * KS * SLICE;
+        const T *first = p.st[0].W + (size_t)wave * (FRONT0 ? p.st[0].K / 256 : KS) * SLICE;
 #pragma unroll
         for (int f = 0; f < 16; ++f) fill(first, f);
     }
@@ -209,8 +227,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             }
         }
     };
-    constexpr int EARLY_XS = DWK == 0 ? MT * NJ : 0;     // stream loads in flight at the first wait
-    if constexpr (DWK == 0) load_stream();
+    constexpr int EARLY_XS = (DWK == 0 && !FRONT0) ? MT * NJ : 0;     // stream loads in flight at the first wait
+    if constexpr (DWK == 0 && !FRONT0) load_stream();                 // (FRONT: the stream is born in this launch)
     __builtin_amdgcn_sched_barrier(0);
     if (tid < BMC) {
         const int m = min(m0 + tid, M - 1), b = m / p.T_, t = m - b * p.T_;
@@ -527,6 +545,37 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             RSTAMP()                               // product done
             rowln_epilogue(st, hs);
             RSTAMP()                               // epilogue done
+        } else if constexpr (kind == ST_FRONT) {
+            // x = bias + Z Wout^T with K = F C (the frontend's output linear, convolution.py:224,235-236; the flatten of (f, c) is a view of the
+            // channel-last frontend output, the weight's columns were permuted at load), then the first block's LayerNorm.  24 slices of 256 k at
+            // F C = 6144: slice ks + 1 is in flight (LDS-DMA into the other hidden image) while slice ks is multiplied; one barrier per slice.
+            // The split-K GEMM + reduction this replaces ran 300 workgroups on all 256 CUs for 50 us; this form streams every weight byte once
+            // per row block, like every other stage.
+            static_assert(decltype(FIRST)::value, "FRONT is a first stage");
+            request_ln_params(st);
+            const int nsl = st.K / 256;
+            auto slice = [&](int ns, int ks) { return st.W + ((size_t)(ns * 8 + wave) * nsl + ks) * SLICE; };
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) xs[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            add_bias_to_stream(st.bias, 1.0f);
+#pragma unroll 1
+            for (int ks = 0; ks < nsl; ++ks) {
+                // here: slice ks has landed and is published, every wave is done with the other image
+                if (ks + 1 < nsl) front_dma(ks + 1);
+                const unsigned char *img = hs + (ks & 1) * IMGH;
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    step(img, xs, 2 * ns, ns + 1 < NS ? slice(ns + 1, ks) : (ks + 1 < nsl ? slice(0, ks + 1) : after), no_side, std::false_type{});
+                if (ks + 1 < nsl) {
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the DMAs of slice ks + 1 are older than the last step's 16 ring loads
+                    lds_fence_barrier();
+                }
+            }
+            RSTAMP()                               // product done
+            rowln_epilogue(st, hs + (nsl & 1) * IMGH);                     // partials in the image the last slice did not use
+            RSTAMP()                               // epilogue done
         } else if constexpr (kind == ST_FFN) {
             // Software pipeline over the 256-wide hidden chunks:   P1(c): hidden(c) = xa W1(c)^T                  (KS steps)
             //                                                      P2(c-1): stream += silu(hidden(c-1)) W2(c-1)^T  (NS steps)  beside
@@ -677,7 +726,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             }
         }
     };
-    auto first_slice = [&](int i) -> const T * { return p.st[i].W + (size_t)wave * KS * SLICE; };
+    auto first_slice = [&](int i) -> const T * { return p.st[i].W + (size_t)wave * ((i == 0 && FRONT0) ? p.st[0].K / 256 : KS) * SLICE; };
     run_stage(std::integral_constant<int, K0>{}, std::true_type{}, p.st[0], K1 >= 0 ? first_slice(1) : first_slice(0));
     run_stage(std::integral_constant<int, K1>{}, std::false_type{}, p.st[1], K2 >= 0 ? first_slice(2) : first_slice(0));
     run_stage(std::integral_constant<int, K2>{}, std::false_type{}, p.st[2], K3 >= 0 ? first_slice(3) : first_slice(0));
@@ -734,6 +783,7 @@ static inline hipError_t launch_rowchain(hipStream_t s, const ChainArgs &a, bool
         if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == -1) return launch_rowchain_cfg<D, 31, ST_ROWLN, ST_FFN, -1, -1, true>(s, a, taps, rows_hint);
         return hipErrorInvalidValue;
     }
+    if (k0 == ST_FRONT && k1 == ST_FFN && k2 == ST_QKV && k3 == -1) return launch_rowchain_cfg<D, 0, ST_FRONT, ST_FFN, ST_QKV, -1, true>(s, a, taps, rows_hint);
     if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_rowchain_cfg<D, 0, ST_FFN, ST_QKV, -1, -1, true>(s, a, taps, rows_hint);
     if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_GLU, -1, -1, true>(s, a, taps, rows_hint);
     // (without the depthwise prologue: conv kernels other than 31 -- the stand-alone depthwise kernel runs before the launch --, COCR_NO_DW_FUSE A/B runs)

@@ -5,7 +5,7 @@
 
 #include "common.hip.h"
 
-enum { ST_ROWLN = 0, ST_FFN = 1, ST_GLU = 2, ST_QKV = 3 };
+enum { ST_ROWLN = 0, ST_FFN = 1, ST_GLU = 2, ST_QKV = 3, ST_FRONT = 4 };
 
 struct ChainStage {
     int kind;
@@ -14,6 +14,7 @@ struct ChainStage {
     const float *bias;     // ROWLN / GLU / QKV: (N); FFN: b1 (FF)
     const float *bias2;    // FFN: b2 (D)
     int N;                 // output columns (D / 2D / 3D) or FF
+    int K;                 // FRONT: depth of the product (F C of the frontend's output linear, a multiple of 256); W is (D, K), its operand ChainArgs::A0 is (M, K)
     float alpha;           // FFN residual factor (already folded into W2; applied to b2 here)
     const float *g1, *b1, *g2, *b2;    // LayerNorm(s) after the residual add (g2 != null: chained, x <- LN1)
     int store_x, store_xn;             // write the fp32 stream / the normalised operand back to global after this stage
@@ -24,7 +25,7 @@ struct ChainStage {
 };
 
 struct ChainArgs {
-    const bf16_t *A0;      // first operand rows (M, D) (unused with the depthwise prologue)
+    const bf16_t *A0;      // first operand rows (M, D) (unused with the depthwise prologue); (M, st[0].K) when the first stage is FRONT
     float *x;              // fp32 residual stream (M, D): read at the start, written by the stages that have store_x
     int x_in_blocked, x_out_blocked;   // the stream in the kernels' own register order instead of row-major: [row block][wave][row tile][column
                                        // tile][lane] float4, i.e. every wave-instruction moves 1 KB of consecutive bytes (row-major, a wave's

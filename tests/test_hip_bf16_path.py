@@ -217,10 +217,10 @@ def test_cfg2_text_logits_against_bf16_oracle(text_case):
     assert d16 < d32
 
 
-@pytest.mark.parametrize('flag', ['COCR_NO_CHAIN', 'COCR_NO_FRONT96', 'COCR_NO_DW_FUSE'])
+@pytest.mark.parametrize('flag', ['COCR_NO_CHAIN', 'COCR_NO_FRONT96', 'COCR_NO_DW_FUSE', 'COCR_NO_FRONT_CHAIN'])
 def test_fast_path_against_per_product_kernels(text_case, flag, monkeypatch):
-    """A/B inside the library: the chain kernels / the fused frontend / the fused depthwise prologue against the
-    one-kernel-per-product forms (same operands, same rounding points, other accumulation orders) on the metric batch."""
+    """A/B inside the library: the chain kernels / the fused frontend / the fused depthwise prologue / the frontend's output linear as the
+    first chain stage (COCR_NO_FRONT_CHAIN: as a split-K GEMM + reduction) against the one-kernel-per-product forms (same operands, same rounding points, other accumulation orders) on the metric batch."""
     tc = text_case('cfg2_text')
     image, lens, idx = tc.batch(0)
     x = torch.from_numpy(image[:, 0]).cuda()
