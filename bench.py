@@ -148,6 +148,7 @@ def kernel_table(hp, n, w, dtype):
         'gemm_ffn_up': ('mfma', 2.0 * M * D * ff),
         'gemm_ffn_down': ('mfma', 2.0 * M * D * ff),
         'ffn_fused': ('mfma', 4.0 * M * D * ff),
+        'ffn_probe': ('mfma', 4.0 * M * D * ff),
         'chain_ffn_qkv': ('mfma', 4.0 * M * D * ff + 6.0 * M * D * D),
         'chain_front_ffn_qkv': ('mfma', 2.0 * M * F * C * D + 4.0 * M * D * ff + 6.0 * M * D * D),
         'chain_attn_out_glu': ('mfma', 6.0 * M * D * D),

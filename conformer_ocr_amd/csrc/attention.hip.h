@@ -301,7 +301,10 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                         for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]); }
                 }
             }
-            // sc = score - m_run (log2 units)
+            // sc = score - m_run (log2 units).  The maxima are inline assembly: the compiler's hazard recogniser does not know that they read what
+            // the matrix instructions above have just written (no hardware interlock either): the scores are tied to this statement, which
+            // holds the wait states of the longest pass (see the LDS-resident kernel below, where the missing wait showed as run-to-run noise)
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
             float tmax = max3_f(sc[0][0], sc[0][1], sc[0][2]);
             tmax = max3_f(tmax, sc[0][3], sc[1][0]);
             tmax = max3_f(tmax, sc[1][1], sc[1][2]);
@@ -506,6 +509,290 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same computation for lines of at most 320 output frames (the metric's 96x1200 lines: 300), bf16, d_head 64: EVERYTHING A
+// (line, head) NEEDS IS RESIDENT IN LDS.  A workgroup (4 waves, one per SIMD, alone on its CU) owns up to 160 queries of one (line, head);
+// K, V (all Tk <= 320 keys) and the 16 ntw + Tk rows of P its queries can touch are fetched ONCE by LDS-DMA (143 KB at T = 300), one
+// barrier publishes them, and from there on the waves never meet again: no per-key-tile staging round, no barriers in the key loop.
+// A wave owns 2 or 3 CONSECUTIVE 16-query tiles and walks the key tiles with all of them at once: the K, V^T and band fragments it reads
+// from LDS serve every tile (consecutive query tiles share all but one of their five band tiles per 32 keys), and the tiles' independent
+// dependency chains (products -> shift -> maximum -> exponentials -> products) interleave in the one wave a SIMD has.
+// The tiled kernel above spends a third of a workgroup's life before its first product and in the staging rounds (cycle stamps: 4.5 k +
+// 5 x 0.65 k of 22 k), and each of its five workgroups per (line, head) stages the same K / V rows again.
+// Band geometry: local band row lr <-> table row (pos_center - i0 - qmax) + lr, qmax = 16 ntw - 1; score (query i0 + iq, key j) reads
+// lr = qmax - iq + j.  For the query tile at local offset iqt and the 32 keys from js: lr = lb + (15 - il + jl), lb = 16 ntw - 16 - iqt + js,
+// i.e. the tiled kernel's shift R^T[15 - il + jl][il] on the 48 band rows from lb.
+constexpr int AF_QT = 10;                          // query tiles (16 queries) per workgroup at most
+constexpr int AF_TK = 320;                         // keys resident at most
+constexpr int AF_SK = 20;                          // row stride (floats) of a wave's shift tile
+constexpr size_t AF_LDS = (size_t)(2 * AF_TK + 16 * AF_QT + AF_TK) * 128 + 4 * 48 * AF_SK * sizeof(float);
+
+template <int NT>
+__device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const unsigned char *vs, const unsigned char *ps, float *sk,
+                                                const bf16x8 (&qq)[3][2], const f32x4 (&u4)[2][2], const f32x4 (&v4)[2][2], bf16_t *ctxh, int ctx_stride,
+                                                int i_first, int lb_first, int Tn, int Tk, float scale, int lane) {
+    typedef bf16_t T;
+    constexpr int KC = 2, DT = 4, RS = 128;
+    const int il = lane & 15, g = lane >> 4;
+    const int fo0 = ((g ^ (il & 7)) << 4), fo1 = (((4 + g) ^ (il & 7)) << 4);        // byte offset of this lane's 16 bytes of k-chunk 0 / 1 in a row = il mod 8
+    // ---- query operands: (q + u) scale and (q + v) scale of this lane's query in each tile
+    bf16x8 qu[NT][KC], qv[NT][KC];
+    {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = (float)qq[t][c][j];
+                    qu[t][c][j] = (T)((x + u4[c][j >> 2][j & 3]) * scale);
+                    qv[t][c][j] = (T)((x + v4[c][j >> 2][j & 3]) * scale);
+                }
+    }
+    f32x4 o[NT][DT], osum[NT];
+    float m_run[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        osum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_run[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[t][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = il == 0 ? (T)1.0f : (T)0.0f;
+
+    for (int j0 = 0; j0 < Tk; j0 += 64) {
+        f32x4 sc[NT][4], keep[NT];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int js = j0 + 32 * half;
+            // band fragments of the NT + 2 band tiles these query tiles touch for the 32 keys from js: tile u <-> band rows lb_first - 16 (NT - 1) + js + 16 u
+            bf16x8 bfr[NT + 2][KC];
+            {
+                const unsigned char *pb0 = ps + (size_t)(lb_first - 16 * (NT - 1) + js + il) * RS;
+#pragma unroll
+                for (int u = 0; u < NT + 2; ++u) {
+                    if (half == 1 && u == 0) continue;                       // (only query tile NT - 1's kept tile would use it)
+                    bfr[u][0] = *reinterpret_cast<const bf16x8 *>(pb0 + u * 16 * RS + fo0);
+                    bfr[u][1] = *reinterpret_cast<const bf16x8 *>(pb0 + u * 16 * RS + fo1);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 negm = {-m_run[t], -m_run[t], -m_run[t], -m_run[t]};     // positional products start from -reference: see the tiled kernel
+#pragma unroll
+                for (int ml = 0; ml < 3; ++ml) {
+                    f32x4 rr;
+                    if (half == 1 && ml == 0) rr = keep[t];                   // band tile 2 of the first half = tile 0 of the second
+                    else {
+                        rr = negm;
+#pragma unroll
+                        for (int c = 0; c < KC; ++c) rr = mma16(bfr[ml + (NT - 1 - t)][c], qv[t][c], rr);
+                    }
+                    if (half == 0 && ml == 2) keep[t] = rr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sk[(16 * ml + 4 * g + r) * AF_SK + il] = rr[r];
+                }
+                // (no waits around the shift: the tile is private to the wave and a wave's LDS operations execute in order, so the reads below
+                // see these writes and the next query tile's writes cannot overtake the reads.  With ONE wave per SIMD a wait here would stop
+                // the SIMD; the first use of the shifted values, the content products, is where the wave waits.)
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[t][2 * half + tl][r] = sk[(15 - il + 16 * tl + 4 * g + r) * AF_SK + il];
+            }
+            // content products on top of the shifted positional scores: the K fragments serve every query tile
+            bf16x8 kf[2][KC];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const unsigned char *kr = ks + (size_t)(js + 16 * tl + il) * RS;
+                kf[tl][0] = *reinterpret_cast<const bf16x8 *>(kr + fo0);
+                kf[tl][1] = *reinterpret_cast<const bf16x8 *>(kr + fo1);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) sc[t][2 * half + tl] = mma16(kf[tl][c], qu[t][c], sc[t][2 * half + tl]);
+        }
+        // ---- one softmax step per 64 keys and query tile (sc = score - m_run, log2 units), as in the tiled kernel
+        bf16x8 pb[NT][2];
+        // The maxima below are inline assembly (max3_f): the compiler's hazard recogniser does not see that they read registers the matrix
+        // instructions above have just written, and the hardware does not interlock a vector read on a matrix result.  The scores are tied
+        // to this statement (so every product is issued before it, every maximum after it) and it holds the wait states of the longest pass.
+        // (Without it the kernel's results varied in the last bit from run to run: a stale score moves only the running reference.)
+#define AF_TIE(t) "+v"(sc[t][0]), "+v"(sc[t][1]), "+v"(sc[t][2]), "+v"(sc[t][3])
+        if constexpr (NT == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : AF_TIE(0));
+        else if constexpr (NT == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : AF_TIE(0), AF_TIE(1));
+        else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : AF_TIE(0), AF_TIE(1), AF_TIE(2));
+#undef AF_TIE
+        // (the steps below run over all query tiles before the next step starts, and the two uniform branches -- keys beyond the line, reference
+        // moved -- are taken once for all tiles: a branch per tile would cut the tiles' chains into basic blocks that cannot interleave)
+        float tmax[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float m = max3_f(sc[t][0][0], sc[t][0][1], sc[t][0][2]);
+            m = max3_f(m, sc[t][0][3], sc[t][1][0]);
+            m = max3_f(m, sc[t][1][1], sc[t][1][2]);
+            m = max3_f(m, sc[t][1][3], sc[t][2][0]);
+            m = max3_f(m, sc[t][2][1], sc[t][2][2]);
+            m = max3_f(m, sc[t][2][3], sc[t][3][0]);
+            m = max3_f(m, sc[t][3][1], sc[t][3][2]);
+            tmax[t] = max3_f(m, sc[t][3][3], sc[t][3][3]);
+        }
+        if (j0 + 64 > Tn) {                                                  // uniform: only the last tile has keys beyond T
+            asm volatile("; keys beyond the line" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (j0 + 16 * tt + 4 * g + r >= Tn) sc[t][tt][r] = -INFINITY;
+                        m = fmaxf(m, sc[t][tt][r]);
+                    }
+                tmax[t] = m;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { const float x = __shfl_xor(tmax[t], 16, 64); tmax[t] = max3_f(tmax[t], x, x); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { const float x = __shfl_xor(tmax[t], 32, 64); tmax[t] = max3_f(tmax[t], x, x); }
+        // Lazy rescaling, per query tile exactly as in the tiled kernel (the reference of a tile moves only when one of ITS queries exceeds it
+        // by more than LAZY; the first key tile sets it) -- a tile whose reference stays gets delta = 0, alpha = 2^-0 = 1: the same bits
+        constexpr float LAZY = 8.0f;
+        bool need[NT], any = j0 == 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { need[t] = j0 == 0 || __builtin_amdgcn_ballot_w64(tmax[t] > LAZY) != 0; any = any || need[t]; }
+        if (any) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float delta = j0 == 0 ? tmax[t] : (need[t] ? fmaxf(tmax[t], 0.f) : 0.f);
+                const float alpha = j0 == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run[t] = j0 == 0 ? tmax[t] : m_run[t] + delta;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) osum[t][r] *= alpha;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[t][tt][r] -= delta;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[t][tt >> 1][4 * (tt & 1) + r] = (T)__builtin_amdgcn_exp2f(sc[t][tt][r]);
+            osum[t] = mma16(ones, pb[t][0], osum[t]);
+            osum[t] = mma16(ones, pb[t][1], osum[t]);
+        }
+        // ---- O^T += V^T P^T: a V^T fragment serves every query tile
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const bf16x8 v0 = load_vt_frag<true>(vs, RS, j0, d, il, g, T()), v1 = load_vt_frag<true>(vs, RS, j0 + 32, d, il, g, T());
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                o[t][d] = mma16(v0, pb[t][0], o[t][d]);
+                o[t][d] = mma16(v1, pb[t][1], o[t][d]);
+            }
+        }
+    }
+    // ---- normalise and store: whole 128-byte rows through the wave's shift tile, as in the tiled kernel
+    unsigned char *stg = reinterpret_cast<unsigned char *>(sk);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float inv = 1.0f / __shfl(osum[t][0], il, 64);                  // the denominator of query il sits in lane il
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const f32x4 r4 = o[t][d] * inv;
+            const bf16x4 w = {(T)r4[0], (T)r4[1], (T)r4[2], (T)r4[3]};
+            *reinterpret_cast<bf16x4 *>(stg + il * 128 + (((2 * d + (g >> 1)) ^ (il & 7)) << 4) + 8 * (g & 1)) = w;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * j + (lane >> 3), ch = lane & 7;
+            const bf16x8 v8 = *reinterpret_cast<const bf16x8 *>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            const int i = i_first + 16 * t + row;
+            if (i < Tn) *reinterpret_cast<bf16x8 *>(ctxh + (size_t)i * ctx_stride + 8 * ch) = v8;
+        }
+        // (the next tile's staging writes follow these reads in the wave's LDS order)
+    }
+}
+
+__global__ __launch_bounds__(256) void relpos_attention_full_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k, const bf16_t *__restrict__ v,
+                                                                    const bf16_t *__restrict__ ptab, const float *__restrict__ ub,
+                                                                    const float *__restrict__ vb, bf16_t *__restrict__ ctx,
+                                                                    int Tn, int Tp, int heads, float scale, int pos_center, int ntw) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+    const int Tk = (Tn + 63) & ~63;                    // keys walked (rows of K / V staged): whole 64-key tiles; rows beyond T are zero in q / k / v
+    const int nbr = 16 * ntw + Tk;                     // band rows this workgroup can touch
+    unsigned char *ks = att_smem, *vs = ks + (size_t)Tk * 128, *ps = vs + (size_t)Tk * 128;
+    float *skew = reinterpret_cast<float *>(ps + (size_t)nbr * 128);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware order: the workgroups of one (line, head) read the same K / V rows
+    const int nqb = gridDim.x, logical = xcd_remap_i(blockIdx.x + nqb * blockIdx.y, nqb * gridDim.y);
+    const int qb = logical % nqb, bh = logical / nqb, b = bh / heads, hh = bh - b * heads;
+    const int i0 = qb * 16 * ntw;                      // first query of this workgroup
+    const int nt_here = min(ntw, (Tn - i0 + 15) >> 4); // its query tiles (the last workgroup of a line may hold fewer)
+    // this wave's consecutive query tiles: nt_here tiles over 4 waves, the first (nt_here % 4) waves take one more
+    const int base = nt_here >> 2, extra = nt_here & 3;
+    const int mine = base + (wave < extra ? 1 : 0), first = wave * base + min(wave, extra);
+    const int i_first = i0 + 16 * first;
+    // ---- its query rows and the head's two bias vectors: requested ahead of the DMAs below (one wait covers everything)
+    bf16x8 qq[3][2];
+    f32x4 u4[2][2], v4[2][2];
+    {
+        const int il = lane & 15, g = lane >> 4;
+        const T *qrows = q + (size_t)bh * Tp * 64;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int iq = min(i_first + 16 * min(t, max(mine - 1, 0)) + il, Tn - 1);      // queries beyond T read row T - 1 and store nothing
+#pragma unroll
+            for (int c = 0; c < 2; ++c) qq[t][c] = load_frag(qrows + (size_t)iq * 64 + c * 32 + 8 * g);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                u4[c][hlf] = *reinterpret_cast<const f32x4 *>(ub + hh * 64 + c * 32 + 8 * g + 4 * hlf);
+                v4[c][hlf] = *reinterpret_cast<const f32x4 *>(vb + hh * 64 + c * 32 + 8 * g + 4 * hlf);
+            }
+    }
+    // ---- K, V and the band -> LDS by DMA: one wave-instruction = 8 rows of 128 bytes; chunk c of row r lands at chunk c ^ (r & 7)
+    {
+        const int r8 = lane >> 3, cs = lane & 7, gch = (cs ^ r8) * 8;       // this lane's row inside a group of 8 and the GLOBAL chunk it fetches
+        const T *kb = k + (size_t)bh * Tp * 64, *vbs = v + (size_t)bh * Tp * 64;
+        for (int rg = wave; rg < Tk / 8; rg += 4) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(ks + rg * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vbs + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(vs + rg * 1024), 16, 0, 0);
+        }
+        const int prow = heads * 64;
+        const T *pb = ptab + (size_t)(pos_center - i0 - (16 * ntw - 1)) * prow + hh * 64;
+        for (int rg = wave; rg < nbr / 8; rg += 4)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + (size_t)(rg * 8 + r8) * prow + gch), (lds_ptr_t)(ps + rg * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (mine == 0) return;
+    const int lb_first = 16 * ntw - 16 - 16 * first;   // band row of R^T row 0 for the first tile and key 0; tile t: 16 t lower; keys from js: + js
+    T *ctxh = ctx + (size_t)b * Tn * (heads * 64) + hh * 64;
+    float *sk = skew + wave * 48 * AF_SK;
+    if (mine == 1) attn_full_tiles<1>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
+    else if (mine == 2) attn_full_tiles<2>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
+    else attn_full_tiles<3>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
 }
 
 template <typename T, int DHP> static inline size_t attention_lds_bytes() {

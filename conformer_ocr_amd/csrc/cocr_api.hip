@@ -162,6 +162,8 @@ struct cocr_model {
     bool no_dw_fuse = false;     // COCR_NO_DW_FUSE=1: depthwise conv as its own launch (A/B)
     int chain_rows = 0;          // rows per workgroup of the row-chain kernels (cocr_set_chain_rows / COCR_CHAIN_ROWS); 0 = by the number of rows
     bool no_front_chain = false; // COCR_NO_FRONT_CHAIN=1: the frontend's output linear as a split-K GEMM + reduction in front of the first chain launch (A/B)
+    bool ffn_probe = false;      // COCR_FFN_PROBE=1: one extra FFN-only row-chain launch per forward (measurement; results discarded)
+    bool att_tiled = false;      // COCR_ATT_TILED=1: the tiled attention kernel also for lines of <= 320 frames (A/B against the LDS-resident one)
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
     std::map<std::string, std::pair<float *, int64_t>> taps;
@@ -175,9 +177,9 @@ struct cocr_model {
 
 static const char *FAMILIES[] = {"frontend_fused", "frontend_conv12", "frontend_dw", "gemm_front_pw", "gemm_front_out", "layernorm",
                                  "gemm_ffn_up", "gemm_ffn_down", "ffn_fused", "chain_ffn_qkv", "chain_front_ffn_qkv", "chain_attn_out_glu", "chain_pw2_ffn_ffn_qkv", "chain_pw2_ffn", "gemm_qkv", "attention", "gemm_attn_out", "gemm_glu",
-                                 "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam", "ctc_loss", "event_pair_overhead"};
+                                 "dwconv", "gemm_pw2", "gemm_decoder", "ctc_greedy", "ctc_beam", "ctc_loss", "ffn_probe", "event_pair_overhead"};
 enum { FAM_FRONT96, FAM_CONV12, FAM_FDW, FAM_FPW, FAM_FOUT, FAM_LN, FAM_FFN_UP, FAM_FFN_DOWN, FAM_FFN_FUSED, FAM_CH_FIRST, FAM_CH_FRONT, FAM_CH_A, FAM_CH_B, FAM_CH_LAST, FAM_QKV, FAM_ATTN, FAM_AOUT, FAM_GLU,
-       FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_LOSS, FAM_EMPTY, FAM_COUNT };
+       FAM_DW, FAM_PW2, FAM_DEC, FAM_GREEDY, FAM_BEAM, FAM_LOSS, FAM_FFN_PROBE, FAM_EMPTY, FAM_COUNT };
 
 static int out_len1(int l) { return l >= 1 ? (l - 1) / 2 + 1 : 0; }
 
@@ -218,6 +220,8 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_FUSED_FFN"); m->no_fused_ffn = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CHAIN"); m->no_chain = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_FRONT_CHAIN"); m->no_front_chain = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_FFN_PROBE"); m->ffn_probe = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_ATT_TILED"); m->att_tiled = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_ROWS"); m->chain_rows = e ? atoi(e) : 0; }
     { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
@@ -863,7 +867,20 @@ extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, d
 
 template <typename T, int DHP>
 static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
-                                   const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, int pos_center, unsigned long long *stamps = nullptr) {
+                                   const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, int pos_center, unsigned long long *stamps = nullptr,
+                                   bool tiled_only = false) {
+    if constexpr (sizeof(T) == 2 && DHP == 64) {
+        // lines of at most 320 frames (the metric's: 300): K, V and the band of a (line, head) resident in LDS, no barriers in the key loop
+        if (dh == DHP && Tn <= AF_TK && !tiled_only && !stamps) {
+            const int ntiles = ceil_div(Tn, 16), nqb = ceil_div(ntiles, AF_QT), ntw = ceil_div(ntiles, nqb), Tk = round_up(Tn, 64);
+            const size_t lds = (size_t)(2 * Tk + 16 * ntw + Tk) * 128 + 4 * 48 * AF_SK * sizeof(float);
+            hipError_t e = raise_lds_limit((const void *)relpos_attention_full_kernel, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(relpos_attention_full_kernel, dim3(nqb, N * heads), dim3(256), lds, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+                               (const bf16_t *)ptab, ub, vb, (bf16_t *)ctx, Tn, Tp, heads, scale * 1.44269504088896340736f, pos_center, ntw);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = attention_lds_bytes<T, DHP>();
     auto kern = relpos_attention_kernel<T, DHP>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
@@ -1119,11 +1136,19 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 { ProfScope ps(m, s, FAM_CH_FIRST); GEMM_TRY(launch(a)); }
                 if (taps && ((rc = tapx(0, "ffn1", tp[0])) || (rc = tap_qkv(0)))) return rc;
             }
+            if (m->ffn_probe) {
+                // measurement only (COCR_FFN_PROBE=1): block 0's first feed-forward module as a launch of its own on real operands (the
+                // frontend output's first M x D values, the stream the launch above left), results discarded (no store flags) -- so that
+                // rocprofv3's matrix-pipe counters can be read for the FFN products alone (tools/ffn_probe.py, profiles/r03_ffn_probe_*)
+                ChainArgs a = base(); a.A0 = (const bf16_t *)zcur; a.nstages = 1;
+                a.st[0] = st_ffn(P.layers[0].ffn[0], P.layers[0].a_ln_g, P.layers[0].a_ln_b, -1, -1);
+                { ProfScope ps(m, s, FAM_FFN_PROBE); GEMM_TRY(launch(a)); }
+            }
             for (int l = 0; l < m->L; ++l) {
                 const LayerW &w = P.layers[l];
                 {
                     ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, (m->stamps && l == 5) ? m->stamps + 192 : nullptr)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, (m->stamps && l == 5) ? m->stamps + 192 : nullptr, m->att_tiled)))
                     if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
                 }
@@ -1185,7 +1210,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, nullptr, m->att_tiled)))
             if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
         }

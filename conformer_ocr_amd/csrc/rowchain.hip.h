@@ -785,6 +785,9 @@ static inline hipError_t launch_rowchain(hipStream_t s, const ChainArgs &a, bool
     }
     if (k0 == ST_FRONT && k1 == ST_FFN && k2 == ST_QKV && k3 == -1) return launch_rowchain_cfg<D, 0, ST_FRONT, ST_FFN, ST_QKV, -1, true>(s, a, taps, rows_hint);
     if (k0 == ST_FFN && k1 == ST_QKV && k2 == -1) return launch_rowchain_cfg<D, 0, ST_FFN, ST_QKV, -1, -1, true>(s, a, taps, rows_hint);
+    // one feed-forward module alone (operand tile + stream in, LayerNorm epilogue, nothing else): the measurement probe of cocr_api.hip
+    // (COCR_FFN_PROBE=1: matrix-pipe counters of the FFN products by themselves, tools/ffn_probe.py)
+    if (k0 == ST_FFN && k1 == -1) return launch_rowchain_cfg<D, 0, ST_FFN, -1, -1, -1, false>(s, a, false, rows_hint);
     if (k0 == ST_ROWLN && k1 == ST_GLU && k2 == -1) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_GLU, -1, -1, true>(s, a, taps, rows_hint);
     // (without the depthwise prologue: conv kernels other than 31 -- the stand-alone depthwise kernel runs before the launch --, COCR_NO_DW_FUSE A/B runs)
     if (k0 == ST_ROWLN && k1 == ST_FFN && k2 == ST_FFN && k3 == ST_QKV) return launch_rowchain_cfg<D, 0, ST_ROWLN, ST_FFN, ST_FFN, ST_QKV, true>(s, a, taps, rows_hint);

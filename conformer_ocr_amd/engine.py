@@ -208,13 +208,26 @@ class HipRecognizer:
         key, host, ev, _keep = handle
         ev.synchronize()
         ints_h, conf_h, cnt = host[0].numpy(), host[1].numpy(), host[2].numpy()
-        out = []
-        for n in range(key[0]):
-            c = int(cnt[n])
-            lab, st, en, cf = ints_h[0, n, :c].tolist(), ints_h[1, n, :c].tolist(), ints_h[2, n, :c].tolist(), conf_h[n, :c].tolist()
-            out.append(list(zip(lab, st, en, cf)))
+        # one conversion per array for the whole batch (per-line slices + tolist: 110 us for 32 lines, after the GPU has finished)
+        cl = cnt[:key[0]].tolist()
+        mx = max(cl) if cl else 0
+        lab, st, en = ints_h[:, :, :mx].tolist()
+        cf = conf_h[:, :mx].tolist()
+        out = [list(zip(lab[n][:c], st[n][:c], en[n][:c], cf[n][:c])) for n, c in enumerate(cl)]
         self._pinned[key].append(host)
         return out
+
+    def collect_labels(self, handle) -> List[np.ndarray]:
+        """Waits for a `_decode_async` handle; per line the int32 label array only (copies: the pinned buffers go back to the pool) --
+        what `predict_string` needs, without building four Python lists per line."""
+        key, host, ev, _keep = handle
+        ev.synchronize()
+        lab, cnt = host[0].numpy()[0], host[2].numpy()
+        cl = cnt[:key[0]].tolist()
+        mx = max(cl) if cl else 0
+        block = lab[:, :mx].copy()
+        self._pinned[key].append(host)
+        return [block[n, :c] for n, c in enumerate(cl)]
 
     def _decode(self, fn, logits: torch.Tensor, out_lens, extra=()) -> List[List[Tuple[int, int, int, float]]]:
         return self.collect(self._decode_async(fn, logits, out_lens, extra))

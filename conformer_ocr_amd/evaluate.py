@@ -299,8 +299,14 @@ def recognize(net, lines: Sequence[np.ndarray], batch_size: int = 32, edge: int 
         beam = net.ctc_decoder.beam_size if isinstance(net.ctc_decoder, BeamDecoder) else 0
         inflight: List[tuple] = []
 
+        lut = net._codec_lut()
+
         def finish(item):
             idx, k, handle, _keep = item
+            if lut is not None:                              # 1:1 codec: one table lookup per line (pred.py predict_string)
+                for i, lab in zip(idx, engines[k].collect_labels(handle)):
+                    out[i] = ''.join(lut[np.minimum(lab, lut.shape[0] - 1)].tolist())
+                return
             for i, locs in zip(idx, engines[k].collect(handle)):
                 out[i] = ''.join(x[0] for x in net.codec.decode(locs))
         stager = _Stager(lines, batches, shard_batches(len(batches), rank, world), depth=streams)

@@ -110,3 +110,41 @@ def test_fused_argmax_is_not_reused_for_other_values_in_the_same_buffer():
         other.copy_(buf)
         got = A.ctc_greedy(other, ol)
         assert [[r[:3] for r in line] for line in got] == [[r[:3] for r in line] for line in want_b]
+
+
+def test_predict_string_table_path_equals_the_record_path():
+    """`predict_string` maps label arrays to characters by one table lookup per line when the codec is 1:1 (pred.py `_codec_lut`); it must
+    return what the reference's loop returns -- the codec's decode over `predict_labels`' records (pred.py:157-164) -- for a codec that
+    knows every label, one that misses some (skipped, as `decode` skips them), one whose graphemes are two characters long, and (fallback:
+    no table) one with multi-label graphemes; greedy and beam decoders; and through `recognize(streams=2)`."""
+    from conformer_ocr_amd.codec import PytorchCodec
+    from conformer_ocr_amd.ctc_decoder import BeamDecoder
+    from conformer_ocr_amd.evaluate import recognize
+    hp = synth.hparams('tiny')
+    state = synth.make_state_dict(hp, seed=7, decoder_gain=8.0)
+    image, lens = synth.make_lines(3, hp.height, 64, seed=7, widths=[64, 37, 50])
+    x, l = torch.from_numpy(image).cuda(), torch.from_numpy(lens)
+    net = _net(hp, state)
+    full = ascii_codec(hp.num_classes)
+    codecs = {
+        'full': full,
+        'partial': PytorchCodec({k: v for k, v in full.c2l.items() if v[0] % 3 != 0}),
+        'digraphs': PytorchCodec({k + k.lower(): v for k, v in full.c2l.items()}),
+        'multi-label': PytorchCodec({**{k: v for k, v in full.c2l.items() if v[0] > 2}, 'Q': [1, 2]}),
+    }
+    seen = set()
+    for name, codec in codecs.items():
+        net.codec = codec
+        for dec in (None, BeamDecoder(4)):
+            if dec is not None:
+                net.ctc_decoder = dec
+            recs = net.predict_labels(x, l)
+            want = [''.join(c for c, _, _, _ in codec.decode(r)) for r in recs]
+            assert net.predict_string(x, l) == want, (name, dec)
+            assert net.collect_strings(net.predict_string_async(x, l)) == want, (name, dec)
+            seen.update(want)
+        assert (net._codec_lut() is None) == (name == 'multi-label')
+    assert len(seen) > 3 and any(seen)
+    lines = [image[i, 0, :, :int(lens[i])] for i in range(3)]
+    net.codec = codecs['partial']
+    assert recognize(net, lines, batch_size=2, streams=2) == recognize(net, lines, batch_size=2, pipelined=False)
