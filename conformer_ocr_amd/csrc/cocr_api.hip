@@ -163,6 +163,7 @@ struct cocr_model {
     int chain_rows = 0;          // rows per workgroup of the row-chain kernels (cocr_set_chain_rows / COCR_CHAIN_ROWS); 0 = by the number of rows
     bool no_front_chain = false; // COCR_NO_FRONT_CHAIN=1: the frontend's output linear as a split-K GEMM + reduction in front of the first chain launch (A/B)
     bool ffn_probe = false;      // COCR_FFN_PROBE=1: one extra FFN-only row-chain launch per forward (measurement; results discarded)
+    int att_resident_min = 192;  // COCR_ATT_RESIDENT_MIN: fewest workgroups for which the LDS-resident attention kernel is chosen (tests: 1)
     bool att_tiled = false;      // COCR_ATT_TILED=1: the tiled attention kernel also for lines of <= 320 frames (A/B against the LDS-resident one)
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
@@ -222,6 +223,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_FRONT_CHAIN"); m->no_front_chain = e && e[0] == '1'; }
     { const char *e = getenv("COCR_FFN_PROBE"); m->ffn_probe = e && e[0] == '1'; }
     { const char *e = getenv("COCR_ATT_TILED"); m->att_tiled = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_ATT_RESIDENT_MIN"); if (e) m->att_resident_min = atoi(e); }
     { const char *e = getenv("COCR_CHAIN_ROWS"); m->chain_rows = e ? atoi(e) : 0; }
     { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
@@ -868,11 +870,14 @@ extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, d
 template <typename T, int DHP>
 static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
                                    const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, int pos_center, unsigned long long *stamps = nullptr,
-                                   bool tiled_only = false) {
+                                   bool tiled_only = false, int resident_min = 192) {
     if constexpr (sizeof(T) == 2 && DHP == 64) {
         // lines of at most 320 frames (the metric's: 300): K, V and the band of a (line, head) resident in LDS, no barriers in the key loop
-        if (dh == DHP && Tn <= AF_TK && !tiled_only && !stamps) {
-            const int ntiles = ceil_div(Tn, 16), nqb = ceil_div(ntiles, AF_QT), ntw = ceil_div(ntiles, nqb), Tk = round_up(Tn, 64);
+        // ... when there are enough (line, head) pairs to give most CUs one of its workgroups: a small batch is served faster by the tiled
+        // kernel's five workgroups per (line, head) on CUs of their own (B = 1: 0.83 ms per forward with this kernel against 0.76 ms)
+        const int ntiles = ceil_div(Tn, 16), nqb = ceil_div(ntiles, AF_QT);
+        if (dh == DHP && Tn <= AF_TK && !tiled_only && !stamps && nqb * N * heads >= resident_min) {
+            const int ntw = ceil_div(ntiles, nqb), Tk = round_up(Tn, 64);
             const size_t lds = (size_t)(2 * Tk + 16 * ntw + Tk) * 128 + 4 * 48 * AF_SK * sizeof(float);
             hipError_t e = raise_lds_limit((const void *)relpos_attention_full_kernel, lds);
             if (e != hipSuccess) return e;
@@ -1148,7 +1153,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 const LayerW &w = P.layers[l];
                 {
                     ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, (m->stamps && l == 5) ? m->stamps + 192 : nullptr, m->att_tiled)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, (m->stamps && l == 5) ? m->stamps + 192 : nullptr, m->att_tiled, m->att_resident_min)))
                     if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
                 }
@@ -1210,7 +1215,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, nullptr, m->att_tiled)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, nullptr, m->att_tiled, m->att_resident_min)))
             if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
         }
