@@ -59,6 +59,12 @@ __device__ __forceinline__ float butterfly4(float a, float b, float c, float d) 
     return ab + cd;                        // rows: a, c, b, d
 }
 
+// hardware workgroup id -> row block such that XCD (id % 8) owns a contiguous range of row blocks (as attention.hip.h: xcd_remap_i)
+__device__ __forceinline__ int xcd_remap_rows(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 template <int D, int MT> constexpr size_t rowchain_lds_bytes() {
     return (size_t)(D / 64) * 16 * MT * 128 + 2 * 4 * (size_t)(16 * MT) * 128 + 4096 + 16 * (size_t)D + 12 * (size_t)(16 * MT) + 64;
 }
@@ -100,11 +106,15 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4, swz = r16 & 7;
-    const int M = p.M, m0 = blockIdx.x * BMC, mend = min(M, m0 + BMC);
+    // XCD-aware order (p.xcd_order): hardware workgroup ids go round the 8 XCDs; the row block a workgroup owns is chosen so that each XCD
+    // holds a contiguous range of row blocks, i.e. of lines -- the same lines whose (line, head) workgroups the attention kernels put on that
+    // XCD: what one launch writes (context rows, GLU output, stream, q / k / v) the next one reads from the same L2
+    const int rblk = p.xcd_order ? xcd_remap_rows(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int M = p.M, m0 = rblk * BMC, mend = min(M, m0 + BMC);
     const int lrow = lane >> 3, cpos = lane & 7;
 #ifdef COCR_CHAIN_STAMPS_BUILD
     int sk = 0;
-#define RSTAMP() { if (p.stamps && blockIdx.x == COCR_STAMP_WG && lane == 0) p.stamps[wave * 64 + sk] = __builtin_readcyclecounter(); ++sk; }
+#define RSTAMP() { if (p.stamps && rblk == COCR_STAMP_WG && lane == 0) p.stamps[wave * 64 + sk] = __builtin_readcyclecounter(); ++sk; }
 #else
 #define RSTAMP()
 #endif
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     // not fit: fragments were parked in scratch memory at the kernel's start, i.e. waited for), and the first product hides them.
     f32x4 xs[MT][NJ];
     // (blocked form: see ChainArgs::x_in_blocked)
-    const size_t xblk = ((size_t)blockIdx.x * 8 + wave) * (MT * NJ) * 256 + lane * 4;      // floats
+    const size_t xblk = ((size_t)rblk * 8 + wave) * (MT * NJ) * 256 + lane * 4;      // floats
     auto load_stream = [&]() {
         if (p.x_in_blocked) {
 #pragma unroll
