@@ -262,3 +262,15 @@ def test_signature_sees_every_kind_of_weight_change():
     changed()
     net.float()
     assert net._signature(dev) == net._signature(dev)
+
+
+def test_training_step_has_no_cpu_fallback():
+    """`net.training_step` (the step behind torch autograd) needs the GPU library like every other compute call; frozen holders say what to do."""
+    hp = synth.hparams('tiny')
+    net = _net(hp)
+    batch = {'image': torch.zeros(1, 1, hp.height, 40), 'seq_lens': torch.tensor([40]), 'target': torch.tensor([1, 2]), 'target_lens': torch.tensor([2])}
+    with pytest.raises(RuntimeError, match='requires_grad_'):
+        net.training_step(batch)
+    net.nn.requires_grad_(True)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net.training_step(batch)
