@@ -128,3 +128,23 @@ def test_pinned_staging_pool_shares_buffers_between_batch_shapes():
     flat_c, _ = pool.take((2, 1, 16, 50), torch.uint8, depth=1)            # flat_b was never given back: a fresh buffer after the wait
     assert flat_c.data_ptr() != flat_b.data_ptr()
     assert _PinnedPool.size_class(3 << 20) == 4 << 20 and _PinnedPool.size_class(1) == 1 << 20
+
+
+def test_configs2_sharding_rehearsed_on_one_gpu():
+    """BASELINE configs[2]: batch = 256 lines of 96x1200 sharded over 8 ranks as independent 32-line batches.  Rehearsed on the one GPU
+    of the box: the eight ranks' shards (`recognize(..., rank=r, world=8)`, the same code path a rank runs; `dist.shard_batches`) are
+    disjoint, cover all 256 lines, give 32 lines each, and every line's string equals the single-rank run's (a line's logits depend on
+    its padded batch only, the batches are the same in every world size) -- metric model's shapes, two blocks."""
+    hp = synth.hparams('cfg2', num_encoder_layers=2)
+    state = synth.make_state_dict(hp, seed=21, decoder_gain=8.0, style='text')
+    net = _net(hp, state, 'bf16')
+    lines = [synth.make_text_lines(1, hp.height, 1200, seed=4000 + i)[0][0, 0] for i in range(256)]
+    whole = recognize(net, lines, batch_size=32, streams=4)
+    assert sorted(whole) == list(range(256))
+    seen = {}
+    for r in range(8):
+        part = recognize(net, lines, batch_size=32, rank=r, world=8, streams=2)
+        assert len(part) == 32 and not (set(part) & set(seen))
+        seen.update(part)
+    assert seen == whole
+    assert len(set(whole.values())) > 100             # (the lines read differently: the comparison is not between empty strings)
