@@ -308,7 +308,7 @@ def test_bucketed_loop_on_the_wide_model(text_case):
     assert f"{rep['chars']}\tCharacters" in rep['report']
 
 
-@pytest.mark.parametrize('n,w', [(3, 40), (2, 300), (5, 640), (3, 1000), (17, 1200), (2, 1277), (32, 1200), (64, 300)])
+@pytest.mark.parametrize('n,w', [(3, 40), (3, 68), (3, 132), (2, 300), (5, 640), (4, 648), (3, 1000), (17, 1200), (2, 1277), (32, 1200), (64, 300)])
 def test_lds_resident_attention_equals_the_tiled_kernel_bit_for_bit(n, w, monkeypatch):
     """Lines of at most 320 output frames, in batches of at least 192 workgroups (24 lines x 4 heads x 2), run `relpos_attention_full_kernel` (K, V and the positional band of a (line, head) resident in LDS,
     2 - 3 query tiles per wave, no barriers in the key loop); COCR_ATT_TILED=1 keeps the tiled kernel.  Same products, same shift, the same
