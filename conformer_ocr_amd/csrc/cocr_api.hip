@@ -165,6 +165,7 @@ struct cocr_model {
     bool ffn_probe = false;      // COCR_FFN_PROBE=1: one extra FFN-only row-chain launch per forward (measurement; results discarded)
     int att_resident_min = 192;  // COCR_ATT_RESIDENT_MIN: fewest workgroups for which the LDS-resident attention kernel is chosen (tests: 1)
     bool att_tiled = false;      // COCR_ATT_TILED=1: the tiled attention kernel also for lines of <= 320 frames (A/B against the LDS-resident one)
+    bool no_kskip = false;       // COCR_NO_KSKIP=1: zero-padded narrow models multiply their zero k-steps too (A/B)
     bool chain_xcd = true;       // COCR_CHAIN_XCD=0: row blocks in plain workgroup order (A/B)
     bool no_chain = false;       // COCR_NO_CHAIN=1: one kernel per GEMM / FFN instead of the row-local chains (A/B measurements)
     bool no_fused_ffn = false;   // COCR_NO_FUSED_FFN=1: keep the two-GEMM feed-forward (A/B measurements)
@@ -225,6 +226,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_FFN_PROBE"); m->ffn_probe = e && e[0] == '1'; }
     { const char *e = getenv("COCR_ATT_TILED"); m->att_tiled = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_XCD"); if (e) m->chain_xcd = e[0] != '0'; }
+    { const char *e = getenv("COCR_NO_KSKIP"); m->no_kskip = e && e[0] == '1'; }
     { const char *e = getenv("COCR_ATT_RESIDENT_MIN"); if (e) m->att_resident_min = atoi(e); }
     { const char *e = getenv("COCR_CHAIN_ROWS"); m->chain_rows = e ? atoi(e) : 0; }
     { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
@@ -1114,7 +1116,8 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
             auto launch = [&](const ChainArgs &a) { return D == 256 ? launch_rowchain_256(s, a, taps, m->chain_rows) : launch_rowchain_512(s, a, taps, m->chain_rows); };
             // the fp32 stream between the chain launches: in the kernels' register order (ChainArgs::x_in_blocked); the first launch reads
             // the row-major stream the frontend's reduction wrote
-            auto base = [&]() { ChainArgs a{}; a.x = x; a.x_in_blocked = 1; a.x_out_blocked = 1; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; a.inv_d = 1.0f / (float)m->rD; a.xcd_order = m->chain_xcd ? 1 : 0; return a; };
+            auto base = [&]() { ChainArgs a{}; a.x = x; a.x_in_blocked = 1; a.x_out_blocked = 1; a.xn = (bf16_t *)xn; a.M = M; a.dh = dh; a.dhp = dhp; a.heads = heads; a.T_ = Tn; a.Tp = Tp; a.inv_d = 1.0f / (float)m->rD; a.xcd_order = m->chain_xcd ? 1 : 0;
+                                 a.kd = (m->padded && !m->no_kskip) ? ceil_div(m->rD, 32) : 8; a.kl = (m->padded && !m->no_kskip) ? ((m->rff - 1) % 256) / 32 + 1 : 8; return a; };
             auto st_rowln = [&](size_t wgt, size_t bias, float alpha, size_t g1, size_t b1) {
                 ChainStage st{}; st.kind = ST_ROWLN; st.W = CWT(wgt); st.bias = F32(bias); st.N = D; st.alpha = alpha;
                 st.g1 = F32(g1); st.b1 = F32(b1); return st; };

@@ -78,11 +78,25 @@ template <int D, int MT, int DWK> constexpr int rowchain_taps_place() {
     return 0;
 }
 
-template <int D, int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS>
+// KD / KL: zero-padded narrow models (cocr_api.hip: set_engine_dims) -- the k-steps (32 k each) of a K = D product and of the FFN's LAST
+// hidden chunk that hold real columns; the k-steps beyond them multiply zeros and are skipped (their weight fragments are still streamed:
+// the ring's bookkeeping stays one shape).  8 / 8 = nothing skipped.  The reference's default model (encoder_dim 144, feed-forward 576 in
+// a 256 / 768-wide engine): 5 / 2.
+template <int D, int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS, int KD = 8, int KL = 8>
 __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     typedef bf16_t T;
     static_assert(D == 256 || D == 512, "encoder_dim of the row-chain kernels");
     static_assert(MT >= 2 && MT <= 6, "16-row tiles per workgroup");
+    static_assert(KD >= 1 && KD <= 8 && KL >= 1 && KL <= 8 && (D == 256 || (KD == 8 && KL == 8)), "skipped k-steps: the 256-wide engine only");
+    typedef std::integral_constant<int, 8> KK8;
+    typedef std::integral_constant<int, KD> KKD;           // K = D products
+    typedef std::integral_constant<int, KL> KKL;           // the second product of the FFN's last hidden chunk
+    typedef KKD KKQ;
+    typedef KKD KKG;
+    typedef KKD KKP1;
+    // the ROWLN stage of the out-proj -> GLU chain multiplies the attention context, whose real columns sit in head slots all over the
+    // padded width ([64 h, 64 h + d_head)): no k-step of it is all zeros
+    typedef std::integral_constant<int, (K1 == ST_GLU) ? 8 : KD> KKR;
     constexpr int BMC = 16 * MT;
     constexpr int KS = D / 256;                // 256-deep k slices of a K = D product
     constexpr int NS = D / 256;                // 256-column steps of an N = D product
@@ -246,7 +260,11 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
         tpos[tid] = t;
     }
     RSTAMP()                                       // 1: loads requested
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(16 + EARLY_XS) : "memory");       // the operand DMAs (older than the ring and stream loads) have landed
+    // the operand DMAs (older than the ring and stream loads) have landed.  The count is the FEWEST loads that can be in flight behind them:
+    // a first step that skips k-steps never reads its last ring slots and the compiler drops those loads (with 16 here and 10 loads issued the
+    // wait let the depthwise window arrive late: wrong rows in the first launch on fresh LDS, right ones by luck afterwards)
+    constexpr int RING0 = 2 * (K0 == ST_ROWLN ? KKR::value : K0 == ST_FFN ? KKP1::value : 8);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RING0 + EARLY_XS) : "memory");
     lds_fence_barrier();
     RSTAMP()                                       // 2: operand tile / window landed
 
@@ -345,10 +363,11 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     // One step: acc[rows][32 columns of this wave] += image[256 k] . ring ; ring <- the 16 fragments at `nxt`.  `side(kk)` is independent VALU
     // work folded into the k-step.  `fresh`: the accumulators start from zero -- the first k-step's MFMAs take the constant 0 as their C
     // operand instead of registers zeroed by v_mov (the VALU is the scarce unit of this kernel).
-    auto step = [&](const unsigned char *img, auto &acc, int c0, const T *nxt, auto &&side, auto FRESH) {      // acc[MT][..]: tiles c0, c0 + 1
+    auto step = [&](const unsigned char *img, auto &acc, int c0, const T *nxt, auto &&side, auto FRESH, auto KKC) {      // acc[MT][..]: tiles c0, c0 + 1
         constexpr bool fresh = decltype(FRESH)::value;
+        constexpr int KK = decltype(KKC)::value;           // k-steps with real columns (the others multiply zeros: skipped)
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
             // row tiles in two halves: half the operand registers live
             constexpr int HT = MT > 3 ? MT / 2 : MT;
 #pragma unroll
@@ -375,6 +394,11 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             }
             side(kk);
             __builtin_amdgcn_sched_barrier(0);               // keep the refill (and the side work) here: the scheduler otherwise sinks all of it to the step's end
+        }
+        if constexpr (KK < 8 && !(COCR_RC_EXP & 128)) {
+#pragma unroll
+            for (int f = 2 * KK; f < 16; ++f) fill(nxt, f);  // the skipped k-steps' ring slots: the next step's fragments all the same
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto no_side = [](int) {};
@@ -449,7 +473,10 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             const int tile = g == 0 ? i0 : g == 1 ? i2 : g == 2 ? i1 : i3;              // which tile's totals this lane's row holds
             *reinterpret_cast<f32x2 *>(pbuf + (16 * tile + r16) * PROW + wave * 8) = (f32x2){ts, tss};
         }
-        if (wait_params && wave < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // this stage's LayerNorm parameters have landed
+        if (wait_params && wave < 4) {      // this stage's LayerNorm parameters have landed (requested before the stage's first step)
+            if constexpr (KD == 8 && KL == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // ... at least one step = 16 younger ring loads lies between
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    // (steps that skip k-steps issue fewer: the compiler drops the dead ones)
+        }
         lds_fence_barrier();
         const float inv_d = p.inv_d;                       // (raw moments: zero-padded columns add nothing, the divisor is the real width)
 #pragma unroll
@@ -535,8 +562,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         const T *nxt = ks + 1 < KS ? slice(ns, ks + 1) : (ns + 1 < NS ? slice(ns + 1, 0) : after);
-                        if (ks == 0) step(xa, acc, 2 * ns, nxt, no_side, std::true_type{});
-                        else step(xa + ks * 4 * PANEL, acc, 2 * ns, nxt, no_side, std::false_type{});
+                        if (ks == 0) step(xa, acc, 2 * ns, nxt, no_side, std::true_type{}, KKR{});
+                        else step(xa + ks * 4 * PANEL, acc, 2 * ns, nxt, no_side, std::false_type{}, KKR{});
                     }
                 add_bias_to_stream(st.bias, 1.0f);
 #pragma unroll
@@ -550,7 +577,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                 for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
-                        step(xa + ks * 4 * PANEL, xs, 2 * ns, ks + 1 < KS ? slice(ns, ks + 1) : (ns + 1 < NS ? slice(ns + 1, 0) : after), no_side, std::false_type{});
+                        step(xa + ks * 4 * PANEL, xs, 2 * ns, ks + 1 < KS ? slice(ns, ks + 1) : (ns + 1 < NS ? slice(ns + 1, 0) : after), no_side, std::false_type{}, KKR{});
             }
             RSTAMP()                               // product done
             rowln_epilogue(st, hs);
@@ -577,7 +604,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                 const unsigned char *img = hs + (ks & 1) * IMGH;
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)
-                    step(img, xs, 2 * ns, ns + 1 < NS ? slice(ns + 1, ks) : (ks + 1 < nsl ? slice(0, ks + 1) : after), no_side, std::false_type{});
+                    step(img, xs, 2 * ns, ns + 1 < NS ? slice(ns + 1, ks) : (ks + 1 < nsl ? slice(0, ks + 1) : after), no_side, std::false_type{}, KK8{});
                 if (ks + 1 < nsl) {
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the DMAs of slice ks + 1 are older than the last step's 16 ring loads
                     lds_fence_barrier();
@@ -628,8 +655,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                 if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (ks == 0) step(xa, acc1, 0, KS > 1 ? w1(c, 1) : then, no_side, std::true_type{});
-                    else step(xa + ks * 4 * PANEL, acc1, 0, ks + 1 < KS ? w1(c, ks + 1) : then, no_side, std::false_type{});
+                    if (ks == 0) step(xa, acc1, 0, KS > 1 ? w1(c, 1) : then, no_side, std::true_type{}, KKP1{});
+                    else step(xa + ks * 4 * PANEL, acc1, 0, ks + 1 < KS ? w1(c, ks + 1) : then, no_side, std::false_type{}, KKP1{});
                 }
                 if (wave >= 4) __builtin_amdgcn_s_setprio(0);
             };
@@ -655,14 +682,14 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                          [&](int kk) {
 #pragma unroll
                              for (int t2 = 0; t2 < 2 * MT; ++t2) if ((t2 * 8 * NS) / (2 * MT) == ns * 8 + kk) silu_tile(t2, hb, std::true_type{});
-                         }, std::false_type{});
+                         }, std::false_type{}, KK8{});
                 RSTAMP()                                                  // P2(c-1) + S(c) done
                 lds_fence_barrier();
                 RSTAMP()                                                  // barrier
             }
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns)                               // P2(last)
-                step(hs + ((nchunks - 1) & 1) * IMGH, xs, 2 * ns, ns + 1 < NS ? w2(nchunks - 1, ns + 1) : after, no_side, std::false_type{});
+                step(hs + ((nchunks - 1) & 1) * IMGH, xs, 2 * ns, ns + 1 < NS ? w2(nchunks - 1, ns + 1) : after, no_side, std::false_type{}, KKL{});
             RSTAMP()                                                      // P2(last) done
             rowln_epilogue(st, hs + (nchunks & 1) * IMGH);               // partials in the hidden image the last product did not read
             RSTAMP()                                                      // epilogue done
@@ -678,8 +705,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const T *nxt = ks + 1 < KS ? slice(s2, ks + 1) : (s2 + 1 < NSTEP ? slice(s2 + 1, 0) : after);
-                    if (ks == 0) step(xa, acc, 0, nxt, no_side, std::true_type{});
-                    else step(xa + ks * 4 * PANEL, acc, 0, nxt, no_side, std::false_type{});
+                    if (ks == 0) step(xa, acc, 0, nxt, no_side, std::true_type{}, KKG{});
+                    else step(xa + ks * 4 * PANEL, acc, 0, nxt, no_side, std::false_type{}, KKG{});
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
@@ -705,8 +732,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const T *nxt = ks + 1 < KS ? slice(s3, ks + 1) : (s3 + 1 < NSTEP ? slice(s3 + 1, 0) : after);
-                    if (ks == 0) step(xa, acc, 0, nxt, no_side, std::true_type{});
-                    else step(xa + ks * 4 * PANEL, acc, 0, nxt, no_side, std::false_type{});
+                    if (ks == 0) step(xa, acc, 0, nxt, no_side, std::true_type{}, KKQ{});
+                    else step(xa + ks * 4 * PANEL, acc, 0, nxt, no_side, std::false_type{}, KKQ{});
                 }
                 unsigned char *tile = hs + (s3 & 1) * (BMC * OS);
                 if constexpr (COCR_RC_EXP & 1024) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[MT - 1][1])); continue; }
@@ -745,11 +772,11 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
 #undef RSTAMP
 }
 
-template <int D, int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS>
+template <int D, int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS, int KD = 8, int KL = 8>
 static inline hipError_t launch_rowchain_mt(hipStream_t s, const ChainArgs &a) {
     constexpr size_t lds = rowchain_lds_bytes<D, MT>() + (rowchain_taps_place<D, MT, DWK>() == 2 ? (size_t)(DWK + 1) * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS of one workgroup");
-    auto kern = rowchain_kernel<D, MT, DWK, K0, K1, K2, K3, TAPS>;
+    auto kern = rowchain_kernel<D, MT, DWK, K0, K1, K2, K3, TAPS, KD, KL>;
     hipError_t e = raise_lds_limit((const void *)kern, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, 16 * MT)), dim3(512), lds, s, a);
@@ -773,9 +800,13 @@ template <int D, int DWK, int K0, int K1, int K2, int K3, bool HAS_TAPS>
 static inline hipError_t launch_rowchain_cfg(hipStream_t s, const ChainArgs &a, bool taps, int rows_hint) {
     const int mt = rowchain_pick_mt<D>(a.M, rows_hint);
     if (taps && !HAS_TAPS) return hipErrorInvalidValue;
+    // the reference's default model in its zero-padded 256 / 768-wide form: 5 of 8 k-steps per K = D product, 2 of 8 in the FFN's last chunk
+    // (no debug instantiation: taps run the full-depth kernels, which compute the same values -- the skipped products are exact zeros)
+    const bool narrow = D == 256 && a.kd == 5 && a.kl == 2 && !taps;
 #define COCR_RC(MTV)                                                                                            \
     if (mt == MTV) {                                                                                            \
         if constexpr (HAS_TAPS) { if (taps) return launch_rowchain_mt<D, MTV, DWK, K0, K1, K2, K3, true>(s, a); } \
+        if constexpr (D == 256) { if (narrow) return launch_rowchain_mt<D, MTV, DWK, K0, K1, K2, K3, false, 5, 2>(s, a); } \
         return launch_rowchain_mt<D, MTV, DWK, K0, K1, K2, K3, false>(s, a);                                     \
     }
     if constexpr (D == 256) { COCR_RC(6) COCR_RC(3) } else { COCR_RC(4) }

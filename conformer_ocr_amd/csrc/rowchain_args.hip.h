@@ -33,6 +33,7 @@ struct ChainArgs {
                                        // rows per workgroup; the buffer holds whole row blocks (cocr_api: workspace).
     bf16_t *xn;            // normalised operand (M, D), written when a stage asks for it
     int M, nstages;
+    int kd, kl;            // zero-padded narrow models: k-steps (of 32) with real columns in a K = D product / in the FFN's last hidden chunk (8 = all)
     int xcd_order;         // row blocks in XCD-contiguous order (rowchain.hip.h); every launch of a forward uses the same setting (blocked stream layout)
     const bf16_t *dw_in;   // depthwise-conv prologue: GLU output (M, D)
     const float *dw_w, *dw_b;      // BatchNorm-folded depthwise taps [k][D] and bias [D]

@@ -326,3 +326,28 @@ def test_lds_resident_attention_equals_the_tiled_kernel_bit_for_bit(n, w, monkey
     monkeypatch.setenv('COCR_ATT_TILED', '1')
     tiled = make_engine(hp, state, 'bf16').forward(x, lens)[0].cpu().numpy()
     np.testing.assert_array_equal(runs[0], tiled)
+
+
+@pytest.mark.parametrize('layers,n,w', [(1, 9, 500), (2, 3, 232), (3, 2, 96), (2, 32, 1200)])
+def test_skipped_zero_k_steps_of_the_padded_default_model_change_no_bit(layers, n, w, monkeypatch):
+    """The reference's default model (encoder_dim 144, feed-forward 576) runs zero-padded to 256 / 768; its row-chain instantiation skips
+    the k-steps that multiply zero columns (5 of 8 per K = D product, 2 of 8 in the FFN's last hidden chunk; NOT in the attention
+    out-projection, whose operand has real columns in every head slot).  A skipped product is an exact zero: COCR_NO_KSKIP=1 (every k-step
+    multiplied) must give the same bits.  Each comparison is the FIRST forward of a fresh engine behind a forward of other data: the first
+    version's load-count waits (`s_waitcnt vmcnt(16)`: 16 ring loads assumed behind a DMA, 10 issued once the compiler dropped the dead ones)
+    read LDS too early, which showed only where the LDS did not already hold the same rows from the launch before."""
+    hp = synth.hparams('cfg1', num_encoder_layers=layers)
+    state = synth.make_state_dict(hp, seed=7, decoder_gain=4.0)
+    image, lens = synth.make_lines(n, hp.height, w, seed=11, widths=[max(40, w - 29 * i) for i in range(n)])
+    x = torch.from_numpy(image[:, 0]).cuda()
+    monkeypatch.setenv('COCR_NO_KSKIP', '1')
+    ref = make_engine(hp, state, 'bf16').forward(x, lens)[0].cpu().numpy()
+    monkeypatch.delenv('COCR_NO_KSKIP')
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 1.0
+    for rep in range(3):
+        other, olens = synth.make_lines(5 + rep, hp.height, 300 + 64 * rep, seed=50 + rep)
+        scr = make_engine(hp, state, 'bf16')
+        scr.forward(torch.from_numpy(other[:, 0]).cuda(), olens)                 # other rows through the same kernels' LDS
+        torch.cuda.synchronize()
+        got = make_engine(hp, state, 'bf16').forward(x, lens)[0].cpu().numpy()   # first forward of a fresh engine
+        np.testing.assert_array_equal(got, ref)
