@@ -42,15 +42,20 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def launch_ranks(n, argv, timeout_s=None):
-    """`python bench.py --gpus N` without a launcher around it: THIS process never touches the GPU (nothing before this point has
-    called HIP; `torch.cuda.device_count()` does not initialise it on this image) and starts N fresh rank processes of this same
-    script -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, exactly what
-    `python -m torch.distributed.run --nproc-per-node N bench.py ...` would give them.  Rank 0's stdout (the ONE JSON line) is
-    forwarded to this process's stdout, every rank's stderr is inherited.  Returns the exit code: 0 only if every rank returned 0 and
-    rank 0 printed a line; the first failing rank's code otherwise (the other ranks are terminated by PID).  No exec, no re-exec."""
+def launch_ranks(n, argv, timeout_s=600.0):
+    """`python bench.py --gpus N` without a launcher around it: this process starts N fresh rank processes of this same script --
+    one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, exactly what
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` would give them -- and does no GPU work itself.  (It counts the
+    devices with `torch.cuda.device_count()`; should that call bring up the HIP runtime in this process on some build, it stays
+    harmless: the ranks are fresh children started with `subprocess.Popen`, never an exec or re-exec of this process.)
+    Rank 0's stdout (the ONE JSON line) is drained by a reader thread WHILE the ranks run (a line longer than the pipe's buffer would
+    otherwise block rank 0 in its write and the launcher in its wait) and forwarded to this process's stdout; every rank's stderr is
+    inherited.  `timeout_s` (`--launch-timeout`, default 600 s): ranks still running then -- e.g. stuck in the RCCL rendezvous -- are
+    named on stderr and ended by PID, exit code 124.  Returns the exit code: 0 only if every rank returned 0 and rank 0 printed a line;
+    the first failing rank's code otherwise (the other ranks are terminated by PID)."""
     import socket
     import subprocess
+    import threading
     if '--dry-run' not in argv:
         import torch
         seen = torch.cuda.device_count()
@@ -66,7 +71,14 @@ def launch_ranks(n, argv, timeout_s=None):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != '--spawn'], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
-    t_end = None if timeout_s is None else time.time() + timeout_s
+    chunks = []
+
+    def drain():
+        for piece in iter(lambda: procs[0].stdout.read(65536), b''):
+            chunks.append(piece)
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    t_end = None if not timeout_s or timeout_s <= 0 else time.time() + timeout_s
     rc, live = 0, set(range(n))
     while live and rc == 0:
         for r in sorted(live):
@@ -76,12 +88,12 @@ def launch_ranks(n, argv, timeout_s=None):
                 if c != 0:
                     sys.stderr.write(f'bench.py: rank {r} exited with code {c}\n')
                     rc = c if c > 0 else 1
-        if t_end is not None and time.time() > t_end:
-            sys.stderr.write(f'bench.py: ranks {sorted(live)} still running after {timeout_s} s\n')
+        if live and rc == 0 and t_end is not None and time.time() > t_end:
+            sys.stderr.write(f'bench.py: ranks {sorted(live)} still running after {timeout_s:g} s (--launch-timeout): ending them\n')
             rc = 124
         if live and rc == 0:
             time.sleep(0.05)
-    for r in live:                                  # a rank failed: the others would wait for it at the next barrier
+    for r in live:                                  # a rank failed or the time is up: the others would wait for it at the next barrier
         procs[r].terminate()
     for r in live:
         try:
@@ -89,7 +101,8 @@ def launch_ranks(n, argv, timeout_s=None):
         except subprocess.TimeoutExpired:
             procs[r].kill()
             procs[r].wait()
-    out = procs[0].stdout.read().decode('utf-8', 'replace') if procs[0].stdout else ''
+    reader.join(timeout=20)
+    out = b''.join(chunks).decode('utf-8', 'replace')
     lines = [ln for ln in out.splitlines() if ln.strip()]
     if rc == 0 and len(lines) != 1:
         sys.stderr.write(f'bench.py: rank 0 printed {len(lines)} lines, expected one\n')
@@ -101,18 +114,19 @@ def launch_ranks(n, argv, timeout_s=None):
 
 
 def _launcher_args(argv):
-    """(gpus, spawn) from the command line without importing anything heavy."""
+    """(gpus, spawn, launch timeout) from the command line without importing anything heavy."""
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--spawn', action='store_true')
+    ap.add_argument('--launch-timeout', type=float, default=600.0)
     a, _ = ap.parse_known_args(argv)
-    return a.gpus, a.spawn
+    return a.gpus, a.spawn, a.launch_timeout
 
 
 if __name__ == '__main__' and 'RANK' not in os.environ:
-    _n, _spawn = _launcher_args(sys.argv[1:])
+    _n, _spawn, _lt = _launcher_args(sys.argv[1:])
     if _n > 1 or _spawn:
-        sys.exit(launch_ranks(_n, sys.argv[1:]))
+        sys.exit(launch_ranks(_n, sys.argv[1:], timeout_s=_lt))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -288,6 +302,9 @@ def dry_run(args, json_fd):
     if rank == args.dry_run_fail_rank:
         sys.stderr.write(f'bench.py: dry-run rank {rank} fails on request\n')
         sys.exit(3)
+    if rank == args.dry_run_hang_rank:
+        sys.stderr.write(f'bench.py: dry-run rank {rank} hangs on request\n')
+        time.sleep(3600)
     if world != args.gpus:
         sys.exit(2)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -297,8 +314,11 @@ def dry_run(args, json_fd):
     dist.all_reduce(ones)
     dist.barrier()
     if rank == 0:
-        os.write(json_fd, (json.dumps({'metric': METRIC, 'value': None, 'unit': 'lines/s', 'n_gpus': world, 'dry_run': True,
-                                       'config': {'ranks_seen': int(ones.item()), 'backend': 'gloo'}}) + '\n').encode())
+        line = (json.dumps({'metric': METRIC, 'value': None, 'unit': 'lines/s', 'n_gpus': world, 'dry_run': True,
+                            'config': {'ranks_seen': int(ones.item()), 'backend': 'gloo'},
+                            'pad': 'x' * int(os.environ.get('COCR_BENCH_DRYRUN_PAD', '0'))}) + '\n').encode()
+        while line:                                  # (a line longer than the pipe's buffer: os.write may take it in pieces)
+            line = line[os.write(json_fd, line):]
     else:
         print(f'rank {rank}: this text must not reach the launcher\'s stdout', flush=True)
     dist.barrier()
@@ -328,6 +348,10 @@ def main():
     ap.add_argument('--spawn', action='store_true', help='start the rank process(es) as fresh children of this process even for --gpus 1 (the path --gpus N > 1 always takes when no launcher set RANK)')
     ap.add_argument('--dry-run', action='store_true', help='launcher rehearsal without a GPU: gloo rendezvous, barrier, all-reduce, a line with value null')
     ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help='(dry run) this rank exits with code 3 before the rendezvous')
+    ap.add_argument('--dry-run-hang-rank', type=int, default=-1, help='(dry run) this rank sleeps instead of joining the rendezvous: what a rank stuck in RCCL init looks like to the launcher')
+    ap.add_argument('--launch-timeout', type=float, default=600.0, help='(launcher) seconds after which ranks that are still running are named on stderr and ended by PID, exit code 124; 0 = never')
+    ap.add_argument('--profile-batch-only', action='store_true', help='(rocprofv3 runs of a mixed-width queue) the queue is reduced to its heaviest batch, the one the roofline leg prices: the profile\'s per-kernel averages are then that shape\'s')
+    ap.add_argument('--no-latency-leg', action='store_true', help='skip the bounded small-batch latency leg (BASELINE configs[4])')
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL / gloo at communicator creation) go to stderr
     sys.stdout.flush()
@@ -406,6 +430,8 @@ def main():
     for bw, idx in plan:
         im, lens = collate(lines, idx, bw)
         batches.append({'x': im[:, 0].contiguous().to(dev), 'lens': lens.numpy().astype(np.int32), 'idx': idx, 'w': bw, 'n': len(idx)})
+    if args.profile_batch_only:
+        batches = [max(batches, key=lambda b: b['n'] * b['w'])]
     NB = len(batches)
     lines_per_cycle = sum(b['n'] for b in batches)
     max_n, max_w = max(b['n'] for b in batches), max(b['w'] for b in batches)
@@ -560,6 +586,37 @@ def main():
                            'what': f'u8 (N,H,W) batches copied from pinned host memory inside the loop ({S} copy streams, 2 staging buffers per '
                                    'stream), forward ingests u8 directly'}
 
+    # ---- small-batch latency (BASELINE configs[4]; reference call site pred.py:148-164): B in {1, 4, 8} lines of the batch, forward + CTC decode
+    # (greedy, beam 16) + read-back of the label records, ONE synchronous call at a time on a replayed hipGraph; p50 / p99 per call.
+    # Bounded: <= 0.4 s per (B, decoder) pair
+    latency = None
+    if rank == 0 and args.config != 'cfg4' and not args.no_extra_legs and not args.no_latency_leg:
+        latency = {'what': 'forward + CTC decode + read-back of the label records, one synchronous call at a time (host wall-clock per call, ms); '
+                           f'lines of 96x{args.width} resident in HBM, hipGraph replay, beam = 16 (softmax inside the decoder)', 'unit': 'ms per call'}
+        b0 = batches[0]
+        eng.set_graph(True)
+        for B in (1, 4, 8):
+            if B > b0['n']:
+                continue
+            xb, lb = b0['x'][:B].contiguous(), b0['lens'][:B].copy()
+            buf = torch.empty((B, eng.out_len(b0['w']), hp.num_classes), dtype=torch.float32, device=dev)
+            for mode in ('greedy', 'beam16'):
+                def call():
+                    lg, ol = eng.forward(xb, lb, out=buf)
+                    return eng.ctc_beam(lg, ol, 16) if mode == 'beam16' else eng.ctc_greedy(lg, ol)
+                for _ in range(8):                       # plain call, capture, replays
+                    call()
+                ts, t_leg = [], time.perf_counter()
+                while len(ts) < 200 and time.perf_counter() - t_leg < 0.4:
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    r_ = call()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                ts = np.sort(np.array(ts))
+                latency[f'B{B}_{mode}'] = {'p50': round(float(ts[len(ts) // 2]), 4), 'p99': round(float(ts[min(len(ts) - 1, int(np.ceil(len(ts) * 0.99)) - 1)]), 4),
+                                           'p50_per_line': round(float(ts[len(ts) // 2]) / B, 4), 'calls': int(len(ts)), 'labels_emitted': int(sum(len(x) for x in r_))}
+        eng.set_graph(use_graph)
+
     # ---- CER (outside the timed region): the compute dtype's greedy strings on the fixture against the reference's fp32 greedy
     # strings of the same padded batches (tests/golden) and against the ground-truth text
     cer = None
@@ -669,13 +726,13 @@ def main():
                                'achieved_tflops_whole_path_padded': j['achieved_tflops_whole_path_padded'],
                                'cer_vs_reference': j['cer_vs_reference'], 'lines_identical_to_reference': (j.get('cer') or {}).get('lines_identical_to_reference'),
                                'fixture_lines': (j.get('cer') or {}).get('lines'),
-                               'roofline': {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_ms', 'cus_occupied', 'frac_of_occupied_cus')},
+                               'roofline': {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_profile', 'avg_ms', 'profiled_batch', 'cus_occupied', 'frac_of_occupied_cus')},
                                'wall_s': round(time.perf_counter() - t_c, 1)}
             except subprocess.TimeoutExpired:
                 others[cfg] = {'error': 'no line within 150 s'}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:        # rank 0 at ANY world size: the host cores' rate beside every line (the other ranks wait at the last barrier)
         cpu = cpu_baseline(hp, state, max_w if args.config != 'cfg4' else 1400, sample_lines=min(32, args.batch) if args.config != 'cfg4' else 8)
 
     if rank == 0:
@@ -697,11 +754,14 @@ def main():
             'achieved_tflops_whole_path_padded': round(value * padded / 1e12, 2),
             'cer_vs_reference': cer['cer_vs_reference'] if cer else None, 'cer': cer,
             **extra,
+            'latency': latency,
             'other_configs': others,
             'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
             'labels_emitted_last_step': int(sum(len(r) for r in recs)),
         }
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+        line = (json.dumps(out) + '\n').encode()
+        while line:
+            line = line[os.write(json_fd, line):]
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

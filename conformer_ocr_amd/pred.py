@@ -124,8 +124,10 @@ class PytorchRecognitionModel(nn.Module):
 
     def invalidate_engine(self) -> None:
         """Forces a re-pack of the device model at the next call.  Not needed after any of: in-place writes, `load_state_dict`
-        (also with `assign=True`), `.to()`, `p.data = new`, replacing a parameter, a buffer or a whole sub-module
-        (`net.nn.decoder = nn.Linear(...)`) -- `_signature` sees all of these."""
+        (also with `assign=True`), `.to()`, `p.data = new`, replacing a parameter, a buffer, a sub-module
+        (`net.nn.decoder = nn.Linear(...)`) or `net.nn` itself -- `_signature` sees all of these.  What it cannot see: a write
+        that bypasses the version counter of a tensor whose address stays the same (raw pointer writes from another library,
+        `tensor.data.copy_()` counts and is seen)."""
         self._sig_tensors = None
         self._engine_sig = None
 
@@ -139,7 +141,7 @@ class PytorchRecognitionModel(nn.Module):
         About 0.15 ms for 478 tensors in 539 modules; `forward` runs it AFTER it has enqueued the launch (the GPU is busy for
         0.8 ms or more) and repeats the call in the rare case that the answer is "changed"."""
         ids = None
-        if self._sig_tensors is not None:
+        if self._sig_tensors is not None and self._sig_tensors[3][0] is self.nn:      # (a replaced `self.nn`: the cached dicts are the old tree's)
             ids = [id(v) for d in self._sig_tensors[1] for v in d.values()]
         if ids is None or ids != self._sig_tensors[2]:
             # first call, or the tree changed.  The cache keeps the modules and tensors it describes alive, so an id in `ids`
@@ -153,7 +155,19 @@ class PytorchRecognitionModel(nn.Module):
         for t in ts:
             ver += t._version
             ptrs.append(t.data_ptr())
-        return (str(device), self.compute_dtype, self._sig_gen, tuple(ptrs), ver)
+        return (str(device), self.compute_dtype, self._sig_gen, id(self.nn), tuple(ptrs), ver)
+
+    def _unchanged_at_a_glance(self) -> bool:
+        """The cheap part of `_signature` (about 40 us): the same module tree object and the same sum of version counters as when
+        the device model was packed.  In-place writes (every optimiser step of a training / validation interleave) show here;
+        `forward` then re-packs BEFORE launching instead of running a whole forward on stale weights first."""
+        st, sig = self._sig_tensors, self._engine_sig
+        if st is None or sig is None or st[3][0] is not self.nn:
+            return False
+        ver = 0
+        for t in st[0]:
+            ver += t._version
+        return ver == sig[-1]
 
     def _pack(self, device: torch.device, sig) -> HipRecognizer:
         eng = HipRecognizer(self.hparams_record, device, self.compute_dtype)
@@ -228,12 +242,18 @@ class PytorchRecognitionModel(nn.Module):
         if eng is None or not line.is_cuda or line.device != eng.device:
             eng = self.engine(line.device if line.is_cuda else None)
             probits, out_lens = eng.forward(line.squeeze(1), lens_np)
-        else:
-            # launch first, look at the parameters while the GPU works (`_signature`): a host-side check of 478 tensors in front of
-            # every launch was 10 % of a 32-line call
+        elif not self._unchanged_at_a_glance():
+            # version counters moved (or the tree object changed): pack first, then launch -- no forward on stale weights
+            eng = self.engine(eng.device)
             probits, out_lens = eng.forward(line.squeeze(1), lens_np)
+        else:
+            # launch first, walk the whole tree while the GPU works (`_signature`: ids, addresses, versions of 478 tensors -- in front
+            # of every launch that was 10 % of a 32-line call); the cheap glance above has already caught in-place writes
+            with torch.no_grad():
+                probits, out_lens = eng.forward(line.squeeze(1), lens_np)
             sig = self._signature(eng.device)
-            if sig != self._engine_sig:                    # the weights changed since the model was packed: pack again, run again
+            if sig != self._engine_sig:                    # a replaced tensor or sub-module: pack again, run again
+                torch.cuda.current_stream(eng.device).synchronize()      # (the old engine's launches are still queued on its buffers)
                 eng = self._pack(eng.device, sig)
                 probits, out_lens = eng.forward(line.squeeze(1), lens_np)
         return probits, torch.from_numpy(out_lens)
@@ -291,12 +311,18 @@ class PytorchRecognitionModel(nn.Module):
         l2c1 = getattr(c, '_l2c1', None)
         if l2c1 is None or getattr(c, 'strict', False):
             return None
-        if getattr(self, '_lut_of', None) is not c or getattr(self, '_lut_n', -1) != len(l2c1):
-            width = max((len(v) for v in l2c1.values()), default=1)
-            lut = np.zeros(max(l2c1, default=0) + 2, dtype=f'<U{max(width, 1)}')
-            for k, v in l2c1.items():
-                lut[k] = v
-            self._lut, self._lut_of, self._lut_n = lut, c, len(l2c1)
+        key = hash(tuple(l2c1.items()))                 # (an in-place edit of the codec's map that keeps its size must rebuild the table)
+        if getattr(self, '_lut_of', None) is not c or getattr(self, '_lut_key', None) != key:
+            top = max(l2c1, default=0)
+            if top > (1 << 20):                         # sparse label ids: no table, `decode()` does it
+                self._lut = None
+            else:
+                width = max((len(v) for v in l2c1.values()), default=1)
+                lut = np.zeros(top + 2, dtype=f'<U{max(width, 1)}')
+                for k, v in l2c1.items():
+                    lut[k] = v
+                self._lut = lut
+            self._lut_of, self._lut_key = c, key
         return self._lut
 
     def predict_string_async(self, line: torch.Tensor, lens: torch.Tensor):
@@ -304,21 +330,21 @@ class PytorchRecognitionModel(nn.Module):
         the read-back of the label records on the current stream and returns a handle; `collect_strings(handle)` waits for
         that batch only -- the next batch's upload and forward can be in flight meanwhile."""
         o, olens = self.forward(line, lens)
-        eng = self._engine
+        eng = self._engine             # the handle carries the engine that owns its pinned records (a re-pack may replace `self._engine` before the collect)
         if isinstance(self.ctc_decoder, GreedyDecoder):
-            return ('device', eng.ctc_greedy_async(o, olens.numpy()))
+            return ('device', eng.ctc_greedy_async(o, olens.numpy()), eng)
         if isinstance(self.ctc_decoder, BeamDecoder):
-            return ('device', eng._decode_async(eng.lib.cocr_ctc_beam, o, olens.numpy(), extra=(int(self.ctc_decoder.beam_size),)))
+            return ('device', eng._decode_async(eng.lib.cocr_ctc_beam, o, olens.numpy(), extra=(int(self.ctc_decoder.beam_size),)), eng)
         o = o.transpose(1, 2).cpu().float().numpy()           # a user-supplied decoder: the reference's own host loop
-        return ('host', [self.ctc_decoder(seq[:, :int(seq_len)]) for seq, seq_len in zip(o, olens)])
+        return ('host', [self.ctc_decoder(seq[:, :int(seq_len)]) for seq, seq_len in zip(o, olens)], None)
 
     def collect_strings(self, handle) -> List[str]:
-        kind, h = handle
+        kind, h, eng = handle
         lut = self._codec_lut() if kind == 'device' else None
         if lut is not None:
             size = lut.shape[0]
-            return [''.join(lut[np.minimum(lab, size - 1)].tolist()) for lab in self._engine.collect_labels(h)]
-        records = self._engine.collect(h) if kind == 'device' else h
+            return [''.join(lut[np.minimum(lab, size - 1)].tolist()) for lab in eng.collect_labels(h)]
+        records = eng.collect(h) if kind == 'device' else h
         return [''.join(x[0] for x in self.codec.decode(locs)) for locs in records]
 
     def step(self, batch: Dict, with_grad: bool = False) -> Dict:

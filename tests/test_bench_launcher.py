@@ -59,6 +59,30 @@ def test_spawn_at_world_one_and_launcher_bypass_under_a_launcher():
     assert r.returncode == 2 and r.stdout.strip() == ''
 
 
+@pytest.mark.timeout(300)
+def test_launcher_times_out_on_a_stuck_rank():
+    """A rank that never reaches the rendezvous (what a rank stuck in RCCL init looks like): after --launch-timeout the launcher names
+    the ranks that are still running, ends them by PID and returns 124 -- no line, no endless wait."""
+    import time
+    t0 = time.time()
+    r = _run(['--gpus', '2', '--dry-run', '--dry-run-hang-rank', '1', '--launch-timeout', '8'], timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert r.stdout.strip() == ''
+    assert 'still running after 8 s' in r.stderr and '[0, 1]' in r.stderr      # rank 0 waits for rank 1 in the rendezvous: both are named
+    assert time.time() - t0 < 90
+
+
+@pytest.mark.timeout(300)
+def test_launcher_drains_a_long_rank0_line():
+    """Rank 0's line may be longer than a pipe buffer (64 KiB): the launcher reads it while the ranks run."""
+    env = dict(_env(), COCR_BENCH_DRYRUN_PAD='200000')
+    r = _run(['--gpus', '2', '--dry-run'], env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) > 200000
+    assert json.loads(lines[0])['config']['ranks_seen'] == 2
+
+
 @pytest.mark.timeout(120)
 def test_launcher_refuses_more_gpus_than_visible():
     import torch
