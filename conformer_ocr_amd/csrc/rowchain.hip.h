@@ -65,15 +65,32 @@ __device__ __forceinline__ int xcd_remap_rows(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Dev build -DCOCR_RC_PAIR=1 (round 4; measured, NOT the default -- DESIGN section 4b): the 48-row form of the 256-wide
+// engine built to be CO-RESIDENT, two workgroups per CU (4 waves per SIMD: <= 128 registers, 80 512 B of LDS each), so that one workgroup's
+// prologue / epilogues / barriers run beside the other's k-steps.  Its weight ring holds 8 fragments (half a step ahead) instead of 16 and
+// its depthwise prologue takes 128 channels per pass.  Bit-identical to the other forms.  At 2 x 250 workgroups on 250 CUs a launch takes
+// 98 us against 77 us for 250 96-row workgroups: two 48-row workgroups stream every weight byte twice through the CU's L1 path, and that
+// costs more than the overlap returns.
+#ifndef COCR_RC_PAIR
+#define COCR_RC_PAIR 0
+#endif
+template <int D, int MT> constexpr bool rowchain_pair_form() { return COCR_RC_PAIR && D == 256 && MT == 3; }
+
+// slack behind the two hidden-chunk images (the q / k / v output tiles' padded rows reach into it)
+template <int D, int MT> constexpr size_t rowchain_slack_bytes() { return rowchain_pair_form<D, MT>() ? 2048 : 4096; }
 template <int D, int MT> constexpr size_t rowchain_lds_bytes() {
-    return (size_t)(D / 64) * 16 * MT * 128 + 2 * 4 * (size_t)(16 * MT) * 128 + 4096 + 16 * (size_t)D + 12 * (size_t)(16 * MT) + 64;
+    return (size_t)(D / 64) * 16 * MT * 128 + 2 * 4 * (size_t)(16 * MT) * 128 + rowchain_slack_bytes<D, MT>() + 16 * (size_t)D + 12 * (size_t)(16 * MT) + 64;
 }
-// Where the depthwise taps of a channel half ((DWK + 1) rows of 256 floats) are staged in LDS: 1 = behind the window inside the hidden-image
+// channels per pass of the depthwise prologue (window + taps of that many channels in LDS at a time): the co-resident form takes 128
+template <int D, int MT> constexpr int rowchain_dw_pass() { return rowchain_pair_form<D, MT>() ? 128 : 256; }
+// Where the depthwise taps of a channel pass ((DWK + 1) rows of floats) are staged in LDS: 1 = behind the window inside the hidden-image
 // area, 2 = in an area of their own behind everything else, 0 = nowhere (no room: every thread loads its own taps from global memory)
 template <int D, int MT, int DWK> constexpr int rowchain_taps_place() {
     if (DWK == 0 || (DWK + 1) % 8 != 0) return 0;
-    constexpr size_t hsb = 2 * 4 * (size_t)(16 * MT) * 128 + 4096, win = (size_t)(16 * MT + DWK - 1) * 512, taps = (size_t)(DWK + 1) * 1024;
+    constexpr size_t cw = rowchain_dw_pass<D, MT>(), rpi = 64 / (cw / 8);
+    constexpr size_t hsb = 2 * 4 * (size_t)(16 * MT) * 128 + rowchain_slack_bytes<D, MT>(), win = ((16 * MT + DWK - 1 + rpi - 1) / rpi) * 1024, taps = (size_t)(DWK + 1) * cw * 4;
     if (win + taps <= hsb) return 1;
+    if (rowchain_pair_form<D, MT>()) return 0;
     if (rowchain_lds_bytes<D, MT>() + taps <= 160 * 1024) return 2;
     return 0;
 }
@@ -83,7 +100,7 @@ template <int D, int MT, int DWK> constexpr int rowchain_taps_place() {
 // the ring's bookkeeping stays one shape).  8 / 8 = nothing skipped.  The reference's default model (encoder_dim 144, feed-forward 576 in
 // a 256 / 768-wide engine): 5 / 2.
 template <int D, int MT, int DWK, int K0, int K1, int K2, int K3, bool TAPS, int KD = 8, int KL = 8>
-__global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
+__global__ __launch_bounds__(512, (rowchain_pair_form<D, MT>() ? 4 : 2)) void rowchain_kernel(ChainArgs p) {
     typedef bf16_t T;
     static_assert(D == 256 || D == 512, "encoder_dim of the row-chain kernels");
     static_assert(MT >= 2 && MT <= 6, "16-row tiles per workgroup");
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     constexpr int SLICE = 16 * 512;            // elements in one step's weight run (16 fragments)
     constexpr int PROW = 80;                   // LayerNorm partials: 8 waves x (sum, sum of squares) per row, padded 64 -> 80 bytes (the 16 rows a
                                                // ds_read_b128 lane group touches then fall on 16 different bank quads)
-    constexpr int HSB = 2 * IMGH + 4096;       // hidden images + slack (output tiles, depthwise window, LayerNorm partials alias them)
+    constexpr int HSB = 2 * IMGH + (int)rowchain_slack_bytes<D, MT>();       // hidden images + slack (output tiles, depthwise window, LayerNorm partials alias them)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *xa = smem;                  // operand image
     unsigned char *hs = smem + IMGX;           // 2 hidden-chunk images
@@ -139,15 +156,18 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     };
 
     constexpr int DWPAD = DWK ? (DWK - 1) / 2 : 0, DWROWS = BMC + 2 * DWPAD;
-    static_assert(DWK == 0 || (size_t)DWROWS * 512 <= (size_t)HSB, "depthwise window (256 channels at a time) must fit the hidden-image area");
+    constexpr int CW = rowchain_dw_pass<D, MT>();          // channels per pass of the depthwise prologue
+    constexpr int WS = CW * 2;                 // bytes per window row
+    constexpr int LPR = CW / 8, RPI = 64 / LPR;            // lanes per window row (16 B each), window rows per wave-instruction
+    constexpr int WINB = ((DWROWS + RPI - 1) / RPI) * 1024;
+    static_assert(DWK == 0 || (size_t)WINB <= (size_t)HSB, "depthwise window (CW channels at a time) must fit the hidden-image area");
     static_assert((size_t)BMC * OSD <= (size_t)HSB && 2 * (size_t)BMC * OS <= (size_t)HSB, "output tiles alias the hidden-image area");
-    // depthwise window of channel half `h`: rows m0 - PAD .. m0 + BMC + PAD - 1 of the GLU output (addresses clamped; frames outside the row's
-    // own line are excluded by the tap range below), [row][512 B] at hs: one wave-instruction = 2 rows
+    // depthwise window of channel pass `h`: rows m0 - PAD .. m0 + BMC + PAD - 1 of the GLU output (addresses clamped; frames outside the row's
+    // own line are excluded by the tap range below), [row][WS bytes] at hs: one wave-instruction = RPI rows
     auto dw_window = [&](int h) {
-        static_assert(DWROWS % 2 == 0, "window rows are loaded in pairs");
-        for (int q2 = wave; q2 < DWROWS / 2; q2 += 8) {
-            const int j = 2 * q2 + (lane >> 5), mrow = min(max(m0 - DWPAD + j, 0), M - 1);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.dw_in + (size_t)mrow * D + h * 256 + (lane & 31) * 8), (lds_ptr_t)(hs + q2 * 1024), 16, 0, 0);
+        for (int q2 = wave; q2 < WINB / 1024; q2 += 8) {
+            const int j = RPI * q2 + lane / LPR, mrow = min(max(m0 - DWPAD + j, 0), M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.dw_in + (size_t)mrow * D + h * CW + (lane % LPR) * 8), (lds_ptr_t)(hs + q2 * 1024), 16, 0, 0);
         }
     };
     // FRONT (first stage = the frontend's output linear, K = F C): its (BMC x 256)-deep operand slices go through the two hidden-image areas,
@@ -186,16 +206,18 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
     dw_f32x2 dw_wt[DWK ? DWK : 1], dw_bias = {0.f, 0.f};
     constexpr int TAPLACE = rowchain_taps_place<D, MT, DWK>();
-    unsigned char *tapa = TAPLACE == 1 ? hs + DWROWS * 512 : smem + rowchain_lds_bytes<D, MT>();
+    unsigned char *tapa = TAPLACE == 1 ? hs + WINB : smem + rowchain_lds_bytes<D, MT>();
+    constexpr int TPI = 256 / CW;                  // tap rows (CW floats) per wave-instruction
     auto dw_taps = [&](int h) {
         if constexpr (DWK != 0 && TAPLACE != 0) {
 #pragma unroll
-            for (int r = wave; r <= DWK; r += 8) {           // (DWK + 1) % 8 == 0: the same number of requests in every wave
-                const float *src = (r < DWK ? p.dw_w + (size_t)r * D : p.dw_b) + h * 256 + lane * 4;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(tapa + r * 1024), 16, 0, 0);
+            for (int r2 = wave; r2 < (DWK + 1) / TPI; r2 += 8) {           // (DWK + 1) % 8 == 0: the same number of requests in every wave
+                const int r = r2 * TPI + lane / (64 / TPI);
+                const float *src = (r < DWK ? p.dw_w + (size_t)r * D : p.dw_b) + h * CW + (lane % (64 / TPI)) * 4;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(tapa + r2 * 1024), 16, 0, 0);
             }
         } else if constexpr (DWK != 0) {
-            const int c = h * 256 + 2 * (tid & 127);
+            const int c = h * CW + 2 * (tid % (CW / 2));
 #pragma unroll
             for (int tau = 0; tau < DWK; ++tau) dw_wt[tau] = *reinterpret_cast<const dw_f32x2 *>(p.dw_w + (size_t)tau * D + c);
             dw_bias = *reinterpret_cast<const dw_f32x2 *>(p.dw_b + c);
@@ -203,22 +225,26 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     };
     auto dw_taps_read = [&]() {                    // after the barrier that publishes the window and the taps
         if constexpr (DWK != 0 && TAPLACE != 0) {
-            const unsigned char *tb = tapa + (tid & 127) * 8;
+            const unsigned char *tb = tapa + (tid % (CW / 2)) * 8;
 #pragma unroll
-            for (int tau = 0; tau < DWK; ++tau) dw_wt[tau] = *reinterpret_cast<const dw_f32x2 *>(tb + tau * 1024);
-            dw_bias = *reinterpret_cast<const dw_f32x2 *>(tb + DWK * 1024);
+            for (int tau = 0; tau < DWK; ++tau) dw_wt[tau] = *reinterpret_cast<const dw_f32x2 *>(tb + tau * (CW * 4));
+            dw_bias = *reinterpret_cast<const dw_f32x2 *>(tb + DWK * (CW * 4));
         }
     };
     RSTAMP()                                       // window / operand tile requested
     dw_taps(0);
     RSTAMP()                                       // taps requested
     // ---- weight ring: the first step's 16 fragments
-    bf16x8 ring[16];
-    auto fill = [&](const T *slice, int f) { ring[f] = *reinterpret_cast<const bf16x8 *>(slice + f * 512 + lane * 8); };
+    // RING = 16: the ring holds the current step's 16 fragments, slot f refilled with fragment f of the next step's run as soon as its
+    // k-step is done.  RING = 8 (the co-resident form): slot f % 8 holds fragment f; after k-step kk < 4 its two slots take fragments
+    // 2 kk + 8 (+ 1) of the CURRENT run, after k-step kk >= 4 fragments 2 (kk - 4) (+ 1) of the next one -- half a step ahead.
+    constexpr int RING = rowchain_pair_form<D, MT>() ? 8 : 16;
+    bf16x8 ring[RING];
+    auto fill = [&](const T *slice, int f) { ring[f % RING] = *reinterpret_cast<const bf16x8 *>(slice + f * 512 + lane * 8); };
+    const T *cur_run = p.st[0].W + (size_t)wave * (FRONT0 ? p.st[0].K / 256 : KS) * SLICE;      // the run whose fragments the ring holds (RING = 8)
     {
-        const T *first = p.st[0].W + (size_t)wave * (FRONT0 ? p.st[0].K / 256 : KS) * SLICE;
 #pragma unroll
-        for (int f = 0; f < 16; ++f) fill(first, f);
+        for (int f = 0; f < RING; ++f) fill(cur_run, f);
     }
     __builtin_amdgcn_sched_barrier(0);
     RSTAMP()                                       // ring requested
@@ -263,7 +289,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
     // the operand DMAs (older than the ring and stream loads) have landed.  The count is the FEWEST loads that can be in flight behind them:
     // a first step that skips k-steps never reads its last ring slots and the compiler drops those loads (with 16 here and 10 loads issued the
     // wait let the depthwise window arrive late: wrong rows in the first launch on fresh LDS, right ones by luck afterwards)
-    constexpr int RING0 = 2 * (K0 == ST_ROWLN ? KKR::value : K0 == ST_FFN ? KKP1::value : 8);
+    constexpr int RING0 = RING == 16 ? 2 * (K0 == ST_ROWLN ? KKR::value : K0 == ST_FFN ? KKP1::value : 8)
+                                     : (2 * (K0 == ST_ROWLN ? KKR::value : K0 == ST_FFN ? KKP1::value : 8) < 8 ? 2 * (K0 == ST_ROWLN ? KKR::value : K0 == ST_FFN ? KKP1::value : 8) : 8);
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RING0 + EARLY_XS) : "memory");
     lds_fence_barrier();
     RSTAMP()                                       // 2: operand tile / window landed
@@ -274,66 +301,69 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
         // time.  thread = one channel pair x BMC / 4 rows (groups of 8); a wave's lanes share their rows, so the boundary test is uniform.
         // Accumulation order per output: bias, then taps ascending (as the stand-alone kernel: bit-identical).
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        const int cp = tid & 127, rq = __builtin_amdgcn_readfirstlane(tid >> 7);
+        constexpr int CPAIRS = CW / 2, NRG = 512 / CPAIRS;    // channel pairs of a pass; row groups the threads split the block's rows into
+        constexpr int RQ = BMC / NRG;                         // rows of one thread
+        constexpr int G = RQ % 8 == 0 ? 8 : (RQ % 6 == 0 ? 6 : 8);      // rows walked together (a window row read serves G outputs)
+        static_assert(BMC % NRG == 0 && RQ >= G, "rows per thread of the depthwise prologue");
+        const int cp = tid % CPAIRS, rq = __builtin_amdgcn_readfirstlane(tid / CPAIRS);
         const int T_ = p.T_;
 #pragma unroll 1
-        for (int h = 0; h < D / 256; ++h) {
-            if (h > 0) {                                     // next channel half: the window area is free after the barrier that ended the previous half
+        for (int h = 0; h < D / CW; ++h) {
+            if (h > 0) {                                     // next channel pass: the window area is free after the barrier that ended the previous one
                 dw_window(h);
                 dw_taps(h);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lds_fence_barrier();
             }
-            const int c = 2 * cp;                            // channel inside the half
+            const int c = 2 * cp;                            // channel inside the pass
             dw_taps_read();
             const f32x2_t bias = dw_bias;
-            // rows of this thread: quarter rq of the block, in groups of 8 (a ragged last group re-does rows of the previous one)
-            constexpr int RQ = BMC / 4;
+            // rows of this thread: group rq of the block, G at a time (a ragged last group re-does rows of the previous one)
 #pragma unroll 1
-            for (int r0 = RQ * rq; r0 < ((COCR_RC_EXP & 2048) ? RQ * rq : RQ * (rq + 1)); r0 += 8) {
-                const int rb = min(r0, RQ * (rq + 1) - 8);
+            for (int r0 = RQ * rq; r0 < ((COCR_RC_EXP & 2048) ? RQ * rq : RQ * (rq + 1)); r0 += G) {
+                const int rb = min(r0, RQ * (rq + 1) - G);
                 const int t0 = __builtin_amdgcn_readfirstlane(tpos[rb]);
-                f32x2_t acc[8];
+                f32x2_t acc[G];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = bias;
-                const unsigned char *wbase = hs + (size_t)rb * 512 + c * 2;
-                if (t0 >= DWPAD && t0 + 7 + DWPAD < T_) {              // all 8 rows inside one line, full tap range
+                for (int i = 0; i < G; ++i) acc[i] = bias;
+                const unsigned char *wbase = hs + (size_t)rb * WS + c * 2;
+                if (t0 >= DWPAD && t0 + (G - 1) + DWPAD < T_) {        // all G rows inside one line, full tap range
 #pragma unroll
-                    for (int rin = 0; rin < 8 + DWK - 1; ++rin) {
-                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * 512);
+                    for (int rin = 0; rin < G + DWK - 1; ++rin) {
+                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * WS);
                         const f32x2_t xf = {(float)xv[0], (float)xv[1]};
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < G; ++i) {
                             const int tau = rin - i;
                             if (tau >= 0 && tau < DWK) { if constexpr (COCR_RC_EXP & 8) { if (tau == 0) acc[i] += xf; } else acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]); }
                         }
                     }
-                } else if (__builtin_amdgcn_readfirstlane(tpos[rb + 7]) == t0 + 7) {
-                    // near a line end, the 8 rows inside one line: the same walk over the window with the rows outside the line read as zero
+                } else if (__builtin_amdgcn_readfirstlane(tpos[rb + G - 1]) == t0 + G - 1) {
+                    // near a line end, the G rows inside one line: the same walk over the window with the rows outside the line read as zero
                     // (a zero tap product leaves the sum as it is: the same values as skipping the tap).  The per-tap form below costs 3 x
                     // the instructions; with one line end per three 96-row blocks it set the kernel's duration: the launch is as long as its
                     // slowest workgroup (timing experiment without the prologue's arithmetic: - 11 us of 63).
 #pragma unroll
-                    for (int rin = 0; rin < 8 + DWK - 1; ++rin) {
+                    for (int rin = 0; rin < G + DWK - 1; ++rin) {
                         const bool ok = (unsigned)(t0 + rin - DWPAD) < (unsigned)T_;     // (uniform)
-                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * 512);
+                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * WS);
                         const f32x2_t xf = {ok ? (float)xv[0] : 0.f, ok ? (float)xv[1] : 0.f};
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < G; ++i) {
                             const int tau = rin - i;
                             if (tau >= 0 && tau < DWK) acc[i] = __builtin_elementwise_fma(dw_wt[tau], xf, acc[i]);
                         }
                     }
                 } else {                                               // rows of two lines: tap tau of row i is in range iff 0 <= t_i + tau - PAD < T
-                    int ti[8];
+                    int ti[G];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) ti[i] = __builtin_amdgcn_readfirstlane(tpos[rb + i]);
+                    for (int i = 0; i < G; ++i) ti[i] = __builtin_amdgcn_readfirstlane(tpos[rb + i]);
 #pragma unroll
-                    for (int rin = 0; rin < 8 + DWK - 1; ++rin) {      // the same walk, the window row masked per output row
-                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * 512);
+                    for (int rin = 0; rin < G + DWK - 1; ++rin) {      // the same walk, the window row masked per output row
+                        const bf16x2 xv = *reinterpret_cast<const bf16x2 *>(wbase + rin * WS);
                         const f32x2_t xr = {(float)xv[0], (float)xv[1]};
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < G; ++i) {
                             const int tau = rin - i;
                             if (tau >= 0 && tau < DWK) {
                                 const bool ok = (unsigned)(ti[i] + tau - DWPAD) < (unsigned)T_;
@@ -344,8 +374,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int row = rb + i, cc = h * 256 + c;
+                for (int i = 0; i < G; ++i) {
+                    const int row = rb + i, cc = h * CW + c;
                     const bf16x2 o = (COCR_RC_EXP & 16384) ? (bf16x2){(T)acc[i][0], (T)acc[i][1]} : (bf16x2){(T)silu_f(acc[i][0]), (T)silu_f(acc[i][1])};
                     *reinterpret_cast<bf16x2 *>(xa + (cc >> 6) * PANEL + row * 128 + ((((cc & 63) >> 3) ^ (row & 7)) << 4) + (cc & 7) * 2) = o;
                     if constexpr (TAPS) {
@@ -353,7 +383,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                     }
                 }
             }
-            lds_fence_barrier();                             // this half of the operand image complete; the window is free
+            lds_fence_barrier();                             // this pass of the operand image complete; the window is free
         }
         load_stream();
         __builtin_amdgcn_sched_barrier(0);
@@ -385,21 +415,30 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                         if constexpr (COCR_RC_EXP & 64) {
                             if (fresh && kk == 0) acc[h0 + i][c0 + j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             asm volatile("" : "+v"(acc[h0 + i][c0 + j]) : "v"(ring[2 * kk + j]), "v"(a[i]));
-                        } else acc[h0 + i][c0 + j] = mma16(ring[2 * kk + j], a[i], (fresh && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[h0 + i][c0 + j]);
+                        } else acc[h0 + i][c0 + j] = mma16(ring[(2 * kk + j) % RING], a[i], (fresh && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[h0 + i][c0 + j]);
                     }
             }
             if constexpr (!(COCR_RC_EXP & 128)) {
-                fill(nxt, 2 * kk);
-                fill(nxt, 2 * kk + 1);
+                if constexpr (RING == 16) {
+                    fill(nxt, 2 * kk);
+                    fill(nxt, 2 * kk + 1);
+                } else if (kk < 4 && kk + 4 < KK) {          // (compile-time: kk is an unrolled constant) this slot is read again at k-step kk + 4
+                    fill(cur_run, 2 * kk + 8);
+                    fill(cur_run, 2 * kk + 9);
+                } else {
+                    fill(nxt, 2 * (kk & 3));
+                    fill(nxt, 2 * (kk & 3) + 1);
+                }
             }
             side(kk);
             __builtin_amdgcn_sched_barrier(0);               // keep the refill (and the side work) here: the scheduler otherwise sinks all of it to the step's end
         }
-        if constexpr (KK < 8 && !(COCR_RC_EXP & 128)) {
+        if constexpr (KK < (RING == 16 ? 8 : 4) && !(COCR_RC_EXP & 128)) {
 #pragma unroll
-            for (int f = 2 * KK; f < 16; ++f) fill(nxt, f);  // the skipped k-steps' ring slots: the next step's fragments all the same
+            for (int f = 2 * KK; f < RING; ++f) fill(nxt, f);  // the skipped k-steps' ring slots: the next step's fragments all the same
             __builtin_amdgcn_sched_barrier(0);
         }
+        cur_run = nxt;
     };
     auto no_side = [](int) {};
     // LayerNorm parameters of a stage -> LDS, requested at the stage's start by waves 0..3 (one array each); the epilogue's vmcnt(16) + barrier
@@ -474,7 +513,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
             *reinterpret_cast<f32x2 *>(pbuf + (16 * tile + r16) * PROW + wave * 8) = (f32x2){ts, tss};
         }
         if (wait_params && wave < 4) {      // this stage's LayerNorm parameters have landed (requested before the stage's first step)
-            if constexpr (KD == 8 && KL == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // ... at least one step = 16 younger ring loads lies between
+            if constexpr (KD == 8 && KL == 8) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RING) : "memory");      // ... at least one step = 16 younger ring loads lies between (8 of them in flight at most with the short ring)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    // (steps that skip k-steps issue fewer: the compiler drops the dead ones)
         }
         lds_fence_barrier();
@@ -606,7 +645,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(ChainArgs p) {
                 for (int ns = 0; ns < NS; ++ns)
                     step(img, xs, 2 * ns, ns + 1 < NS ? slice(ns + 1, ks) : (ks + 1 < nsl ? slice(0, ks + 1) : after), no_side, std::false_type{}, KK8{});
                 if (ks + 1 < nsl) {
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the DMAs of slice ks + 1 are older than the last step's 16 ring loads
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RING) : "memory");      // the DMAs of slice ks + 1 are older than the last step's 16 ring loads
                     lds_fence_barrier();
                 }
             }
