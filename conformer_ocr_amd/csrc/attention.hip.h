@@ -528,11 +528,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 constexpr int AF_QT = 10;                          // query tiles (16 queries) per workgroup at most
 constexpr int AF_TK = 320;                         // keys resident at most
 constexpr int AF_SK = 20;                          // row stride (floats) of a wave's shift tile
-constexpr size_t AF_LDS = (size_t)(2 * AF_TK + 16 * AF_QT + AF_TK) * 128 + 4 * 48 * AF_SK * sizeof(float);
+constexpr int AF_WAVES = 8;                        // waves per workgroup: two per SIMD (round 4; the first form had one per SIMD with up to three query tiles)
+constexpr int AF_SROWS = 32;                       // rows of a wave's shift tile (the 48 band rows of a step go through it in two overlapping rounds)
+constexpr size_t AF_LDS = (size_t)(2 * AF_TK + 16 * AF_QT + AF_TK) * 128 + AF_WAVES * AF_SROWS * AF_SK * sizeof(float);
+static_assert(AF_LDS <= 160 * 1024, "LDS of the resident attention kernel");
 
 template <int NT>
 __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const unsigned char *vs, const unsigned char *ps, float *sk,
-                                                const bf16x8 (&qq)[3][2], const f32x4 (&u4)[2][2], const f32x4 (&v4)[2][2], bf16_t *ctxh, int ctx_stride,
+                                                const bf16x8 (&qq)[2][2], const f32x4 (&u4)[2][2], const f32x4 (&v4)[2][2], bf16_t *ctxh, int ctx_stride,
                                                 int i_first, int lb_first, int Tn, int Tk, float scale, int lane) {
     typedef bf16_t T;
     constexpr int KC = 2, DT = 4, RS = 128;
@@ -594,16 +597,18 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
                         for (int c = 0; c < KC; ++c) rr = mma16(bfr[ml + (NT - 1 - t)][c], qv[t][c], rr);
                     }
                     if (half == 0 && ml == 2) keep[t] = rr;
+                    // The shift tile holds 32 rows: band rows 0..31 are written, the first 16 keys' scores read (rows 15 - il + [0, 16) of them),
+                    // then band rows 32..47 overwrite rows 0..15 and the second 16 keys' scores are read (rows 31 - il + [0, 16) mod 32).
+                    // No waits around any of it: the tile is private to the wave and a wave's LDS operations execute in order, so every read
+                    // sees the writes before it and no write overtakes a read.  The first use of the shifted values, the content products, is
+                    // where the wave waits.
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sk[(16 * ml + 4 * g + r) * AF_SK + il] = rr[r];
+                    for (int r = 0; r < 4; ++r) sk[((16 * ml + 4 * g + r) & (AF_SROWS - 1)) * AF_SK + il] = rr[r];
+                    if (ml >= 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[t][2 * half + ml - 1][r] = sk[((15 - il + 16 * (ml - 1) + 4 * g + r) & (AF_SROWS - 1)) * AF_SK + il];
+                    }
                 }
-                // (no waits around the shift: the tile is private to the wave and a wave's LDS operations execute in order, so the reads below
-                // see these writes and the next query tile's writes cannot overtake the reads.  With ONE wave per SIMD a wait here would stop
-                // the SIMD; the first use of the shifted values, the content products, is where the wave waits.)
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[t][2 * half + tl][r] = sk[(15 - il + 16 * tl + 4 * g + r) * AF_SK + il];
             }
             // content products on top of the shifted positional scores: the K fragments serve every query tile
             bf16x8 kf[2][KC];
@@ -730,7 +735,7 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
     }
 }
 
-__global__ __launch_bounds__(256) void relpos_attention_full_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k, const bf16_t *__restrict__ v,
+__global__ __launch_bounds__(64 * AF_WAVES) void relpos_attention_full_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k, const bf16_t *__restrict__ v,
                                                                     const bf16_t *__restrict__ ptab, const float *__restrict__ ub,
                                                                     const float *__restrict__ vb, bf16_t *__restrict__ ctx,
                                                                     int Tn, int Tp, int heads, float scale, int pos_center, int ntw) {
@@ -747,18 +752,20 @@ __global__ __launch_bounds__(256) void relpos_attention_full_kernel(const bf16_t
     const int qb = logical % nqb, bh = logical / nqb, b = bh / heads, hh = bh - b * heads;
     const int i0 = qb * 16 * ntw;                      // first query of this workgroup
     const int nt_here = min(ntw, (Tn - i0 + 15) >> 4); // its query tiles (the last workgroup of a line may hold fewer)
-    // this wave's consecutive query tiles: nt_here tiles over 4 waves, the first (nt_here % 4) waves take one more
-    const int base = nt_here >> 2, extra = nt_here & 3;
+    // this wave's consecutive query tiles: nt_here (<= 10) tiles over 8 waves, the first (nt_here % 8) waves take one more -- waves w and
+    // w + 4 share a SIMD, so at 10 tiles the SIMDs hold 3, 3, 2, 2 tiles in two waves each (one wave's waits are the other's issue slots)
+    static_assert(AF_QT <= 2 * AF_WAVES, "at most two query tiles per wave");
+    const int base = nt_here / AF_WAVES, extra = nt_here % AF_WAVES;
     const int mine = base + (wave < extra ? 1 : 0), first = wave * base + min(wave, extra);
     const int i_first = i0 + 16 * first;
     // ---- its query rows and the head's two bias vectors: requested ahead of the DMAs below (one wait covers everything)
-    bf16x8 qq[3][2];
+    bf16x8 qq[2][2];
     f32x4 u4[2][2], v4[2][2];
     {
         const int il = lane & 15, g = lane >> 4;
         const T *qrows = q + (size_t)bh * Tp * 64;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < 2; ++t) {
             const int iq = min(i_first + 16 * min(t, max(mine - 1, 0)) + il, Tn - 1);      // queries beyond T read row T - 1 and store nothing
 #pragma unroll
             for (int c = 0; c < 2; ++c) qq[t][c] = load_frag(qrows + (size_t)iq * 64 + c * 32 + 8 * g);
@@ -775,13 +782,13 @@ __global__ __launch_bounds__(256) void relpos_attention_full_kernel(const bf16_t
     {
         const int r8 = lane >> 3, cs = lane & 7, gch = (cs ^ r8) * 8;       // this lane's row inside a group of 8 and the GLOBAL chunk it fetches
         const T *kb = k + (size_t)bh * Tp * 64, *vbs = v + (size_t)bh * Tp * 64;
-        for (int rg = wave; rg < Tk / 8; rg += 4) {
+        for (int rg = wave; rg < Tk / 8; rg += AF_WAVES) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(ks + rg * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vbs + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(vs + rg * 1024), 16, 0, 0);
         }
         const int prow = heads * 64;
         const T *pb = ptab + (size_t)(pos_center - i0 - (16 * ntw - 1)) * prow + hh * 64;
-        for (int rg = wave; rg < nbr / 8; rg += 4)
+        for (int rg = wave; rg < nbr / 8; rg += AF_WAVES)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + (size_t)(rg * 8 + r8) * prow + gch), (lds_ptr_t)(ps + rg * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -789,10 +796,9 @@ __global__ __launch_bounds__(256) void relpos_attention_full_kernel(const bf16_t
     if (mine == 0) return;
     const int lb_first = 16 * ntw - 16 - 16 * first;   // band row of R^T row 0 for the first tile and key 0; tile t: 16 t lower; keys from js: + js
     T *ctxh = ctx + (size_t)b * Tn * (heads * 64) + hh * 64;
-    float *sk = skew + wave * 48 * AF_SK;
+    float *sk = skew + wave * AF_SROWS * AF_SK;
     if (mine == 1) attn_full_tiles<1>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
-    else if (mine == 2) attn_full_tiles<2>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
-    else attn_full_tiles<3>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
+    else attn_full_tiles<2>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
 }
 
 template <typename T, int DHP> static inline size_t attention_lds_bytes() {

@@ -882,10 +882,10 @@ static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k,
         const int ntiles = ceil_div(Tn, 16), nqb = ceil_div(ntiles, AF_QT);
         if (dh == DHP && Tn <= AF_TK && !tiled_only && !stamps && nqb * N * heads >= resident_min) {
             const int ntw = ceil_div(ntiles, nqb), Tk = round_up(Tn, 64);
-            const size_t lds = (size_t)(2 * Tk + 16 * ntw + Tk) * 128 + 4 * 48 * AF_SK * sizeof(float);
+            const size_t lds = (size_t)(2 * Tk + 16 * ntw + Tk) * 128 + AF_WAVES * AF_SROWS * AF_SK * sizeof(float);
             hipError_t e = raise_lds_limit((const void *)relpos_attention_full_kernel, lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(relpos_attention_full_kernel, dim3(nqb, N * heads), dim3(256), lds, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+            hipLaunchKernelGGL(relpos_attention_full_kernel, dim3(nqb, N * heads), dim3(64 * AF_WAVES), lds, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
                                (const bf16_t *)ptab, ub, vb, (bf16_t *)ctx, Tn, Tp, heads, scale * 1.44269504088896340736f, pos_center, ntw);
             return hipGetLastError();
         }
