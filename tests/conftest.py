@@ -29,7 +29,7 @@ def load_case(meta, name):
     m = meta[name]
     hp = HParams(**m['hparams'])
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
-    state = synth.make_state_dict(hp, seed=m['seed'], decoder_gain=m['decoder_gain'])
+    state = synth.make_state_dict(hp, seed=m['seed'], decoder_gain=m['decoder_gain'], style=m.get('weight_style', 'plain'))
     state['decoder.bias'] = g['decoder_bias']
     image, lens = synth.make_lines(m['N'], hp.height, m['W'], seed=m['line_seed'], widths=m['widths'])
     return hp, state, image, lens, g

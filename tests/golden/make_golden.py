@@ -96,12 +96,14 @@ def margins(logits):
 
 
 def run_case(meta, name, hp, seed, n, W, widths=None, with_taps=False, head=None, gain=8.0,
-             line_seed=None, reuse=None):
-    """One fixture: seeded weights (+ calibrated decoder bias) and lines -> reference outputs."""
+             line_seed=None, reuse=None, style='plain'):
+    """One fixture: seeded weights (+ calibrated decoder bias) and lines -> reference outputs.
+    style='text': the encoder draws re-scaled as in the text fixtures (synth.make_state_dict: a random-weight encoder that is local instead
+    of 90 % frame-independent), the decoder still random (gain) with the calibrated bias -- logits with a usable top-2 margin on most frames."""
     line_seed = seed if line_seed is None else line_seed
     image, lens = synth.make_lines(n, hp.height, W, seed=line_seed, widths=widths)
     if reuse is None:
-        state = synth.make_state_dict(hp, seed=seed, decoder_gain=gain)
+        state = synth.make_state_dict(hp, seed=seed, decoder_gain=gain, style=style)
         enc, _ = build_reference(hp, state)
         state['decoder.bias'] = calibrate_decoder_bias(enc, state, image, lens)
         enc, dec = build_reference(hp, state)
@@ -120,7 +122,9 @@ def run_case(meta, name, hp, seed, n, W, widths=None, with_taps=False, head=None
             out['tap:' + k] = v.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     lab = out['labels']
-    meta[name] = {'hparams': hp.as_dict(), 'seed': seed, 'line_seed': line_seed, 'decoder_gain': gain, 'N': n, 'W': W,
+    mg = margins(logits)
+    meta[name] = {'hparams': hp.as_dict(), 'seed': seed, 'line_seed': line_seed, 'decoder_gain': gain, 'weight_style': style, 'N': n, 'W': W,
+                  'margin_share_gt_0p7': float((mg > 0.7).mean()), 'margin_median': float(np.median(mg)),
                   'widths': [int(x) for x in lens], 'sha256_logits': hashlib.sha256(logits.tobytes()).hexdigest(),
                   'distinct_labels': int(len(np.unique(lab))), 'blank_share': float((lab == 0).mean()),
                   'margin_q01': float(np.quantile(margins(logits), 0.01))}
@@ -278,6 +282,18 @@ def long_case(meta):
     print('tiny_long', meta['tiny_long']['frames'], 'frames')
 
 
+def cfg2_cases(meta):
+    """cfg2: the metric's configuration (D=256, L=12, h=4, C=256), batch 32 x 96x1200: full logits of lines 0..3, argmax labels + top-2
+    margins of all 32 lines.  Round 4: 'text'-style encoder draws under the random decoder -- with the plain draws 9 - 12 %
+    of the frames had a top-2 margin above the bf16 band (the label comparison of the bf16 mode was close to vacuous and 7 % of all frame
+    labels flipped); the ratio of bf16 noise to margin does not depend on the decoder gain, only on how frame-dependent the encoder output is."""
+    hp2 = synth.hparams('cfg2')
+    reuse = run_case(meta, 'cfg2', hp2, 1236, 32, 1200, head=4, style='text')
+    # cfg2 ragged: 6 lines of mixed widths right-padded to 1200 (padding-leak case at full size), same weights
+    run_case(meta, 'cfg2_ragged', hp2, 1236, 6, 1200, widths=[1200, 1111, 903, 640, 417, 1200], head=2,
+             line_seed=1237, reuse=reuse, style='text')
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -288,10 +304,10 @@ def main():
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
-    if len(sys.argv) > 1 and sys.argv[1] in ('tiny2', 'long', 'text1'):      # only that fixture, merged into the existing meta.json
+    if len(sys.argv) > 1 and sys.argv[1] in ('tiny2', 'long', 'text1', 'cfg2'):      # only that fixture, merged into the existing meta.json
         with open(os.path.join(HERE, 'meta.json')) as fp:
             meta = json.load(fp)
-        {'tiny2': tiny2_case, 'long': long_case, 'text1': text_case_cfg1}[sys.argv[1]](meta)
+        {'tiny2': tiny2_case, 'long': long_case, 'text1': text_case_cfg1, 'cfg2': cfg2_cases}[sys.argv[1]](meta)
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
@@ -310,13 +326,7 @@ def main():
     hp1 = synth.hparams('cfg1')
     _, enc1, _ = run_case(meta, 'cfg1', hp1, 1235, 4, 512, widths=[512, 400, 300, 512])
     meta['cfg1']['n_params_encoder'] = int(sum(p.numel() for p in enc1.parameters()))
-    # cfg2: the metric's configuration (D=256, L=12, h=4, C=256), batch 32 x 96x1200:
-    # full logits of lines 0..3, argmax labels + top-2 margins of all 32 lines
-    hp2 = synth.hparams('cfg2')
-    reuse = run_case(meta, 'cfg2', hp2, 1236, 32, 1200, head=4)
-    # cfg2 ragged: 6 lines of mixed widths right-padded to 1200 (padding-leak case at full size), same weights
-    run_case(meta, 'cfg2_ragged', hp2, 1236, 6, 1200, widths=[1200, 1111, 903, 640, 417, 1200], head=2,
-             line_seed=1237, reuse=reuse)
+    cfg2_cases(meta)
     # cfg4 (wide conformer D=512, L=16, h=8): 3 lines of bucketed widths padded to 1400
     hp4 = synth.hparams('cfg4')
     run_case(meta, 'cfg4', hp4, 1238, 3, 1400, widths=[1400, 1256, 1208], head=1)

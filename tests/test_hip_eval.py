@@ -134,8 +134,8 @@ def test_configs2_sharding_rehearsed_on_one_gpu():
     """BASELINE configs[2]: batch = 256 lines of 96x1200 sharded over 8 ranks as independent 32-line batches.  Rehearsed on the one GPU
     of the box: the eight ranks' shards (`recognize(..., rank=r, world=8)`, the same code path a rank runs; `dist.shard_batches`) are
     disjoint, cover all 256 lines, give 32 lines each, and every line's string equals the single-rank run's (a line's logits depend on
-    its padded batch only, the batches are the same in every world size) -- metric model's shapes, two blocks."""
-    hp = synth.hparams('cfg2', num_encoder_layers=2)
+    its padded batch only, the batches are the same in every world size) -- the metric's model itself (12 blocks)."""
+    hp = synth.hparams('cfg2')
     state = synth.make_state_dict(hp, seed=21, decoder_gain=8.0, style='text')
     net = _net(hp, state, 'bf16')
     lines = [synth.make_text_lines(1, hp.height, 1200, seed=4000 + i)[0][0, 0] for i in range(256)]

@@ -17,19 +17,28 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 1e-3
 BF16_DEV = 0.30          # bf16 operands, fp32 accumulate + fp32 residual stream, logits of magnitude ~20 (decoder gain 8)
 BF16_MARGIN = 0.7        # constant label filter of the random-weight fixtures
-# Per fixture (measured on MI355X, gpurun_out/parity.jsonl of round 2): logit deviation bound = 1.3 x measured; the share of frames the
-# margin filter leaves to the label comparison (a floor: the comparison must not become vacuous) and a cap on label differences over ALL
-# frames (flat random-weight logits: most margins are a few bf16 roundings wide).  The reference's default model (cfg1, D = 144, zero-
-# padded layout) and the wide model (cfg4) sit above the common 0.30.
+# Per fixture (measured on MI355X, gpurun_out/parity.jsonl of rounds 2 - 4): logit deviation bound = 1.3 x measured; the label filter is
+# max(0.7, 2 x bound) (`bf16_margin`: a frame beyond it cannot legitimately flip); a floor on the share of frames that filter leaves to the
+# label comparison (it must not become vacuous) and a cap on label differences over ALL frames = 1.5 x measured.  cfg2 / cfg2_ragged
+# (round 4): 'text'-style encoder draws under the random decoder -- 57 % / 64 % of the frames pass the filter (plain draws: 9 - 12 %) and
+# 2.7 % / 2.3 % of all frame labels differ (plain draws: 7 %); that ratio does not depend on the decoder gain.  String identity rests on
+# the text fixtures (tests/test_hip_bf16_path.py).
 BF16_CASES = {
-    #               dev bound, measured dev, min checked share, max label differences over all frames
+    #               dev bound, measured dev, min checked share, max label differences over all frames (measured)
     'tiny':        (0.29, 0.218, 0.70, 2),
     'tiny2':       (0.17, 0.127, 0.60, 4),
-    'cfg1':        (0.40, 0.303, 0.40, 110),
-    'cfg2':        (0.30, 0.237, 0.09, 900),
-    'cfg2_ragged': (0.30, 0.244, 0.20, 110),
-    'cfg4':        (0.38, 0.288, 0.24, 80),
+    'cfg1':        (0.40, 0.311, 0.35, 110),      # 72 of 512
+    'cfg2':        (0.35, 0.272, 0.50, 390),      # 260 of 9600
+    'cfg2_ragged': (0.38, 0.292, 0.50, 63),       # 42 of 1800
+    'cfg4':        (0.38, 0.286, 0.20, 75),       # 49 of 1050
 }
+
+
+def bf16_margin(name):
+    """Label filter of a fixture: at least twice its logit-deviation bound (a frame whose top-2 margin exceeds it cannot legitimately flip)."""
+    return max(BF16_MARGIN, 2.0 * BF16_CASES[name][0]) if name in BF16_CASES else BF16_MARGIN
+
+
 LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
 
 
@@ -81,7 +90,7 @@ def _check_case(case, name, dtype, n=None):
     if dtype == 'fp32':
         sel = margins > 2 * FP32_TOL
     else:
-        sel = margins > BF16_MARGIN
+        sel = margins > bf16_margin(name)
     mism = int((labels[sel] != g['labels'][:n][sel]).sum())
     mism_all = int((labels != g['labels'][:n]).sum())
     _log(f'{name}_{dtype}', {'max_abs_logit_dev': dev, 'frames': int(sel.size), 'frames_checked': int(sel.sum()), 'label_mismatch': mism,
@@ -202,7 +211,7 @@ def test_small_batch_form_of_the_chain_kernels(case):
     BITS as lines 0..3 of the full 32-line batch computed by the 96-row form (identical arithmetic per row)."""
     hp, state, image, lens, g = case('cfg2')
     dev, mism, eng, small, _ = _check_case(case, 'cfg2', 'bf16', n=4)
-    assert mism == 0 and dev <= BF16_DEV
+    assert mism == 0 and dev <= BF16_CASES['cfg2'][0]
     _, full, _ = run_hip(hp, state, image, lens, 'bf16')
     np.testing.assert_array_equal(small, full[:4])
 
