@@ -158,6 +158,7 @@ struct cocr_model {
     bool no_pad = false;         // COCR_NO_PAD=1: never run a narrow model as a zero-padded 256-wide one
     bool beam_ref = false;       // COCR_BEAM_REF=1: the exhaustive beam kernel (all beam x C candidates per frame) also for <= 256 classes
     bool no_front96 = false;     // COCR_NO_FRONT96=1: frontend conv stages as separate kernels (A/B)
+    bool no_front32 = false;     // COCR_NO_FRONT32=1: 32 conv channels: the pointwise conv as a GEMM launch of its own (A/B)
     bool no_conv_mfma = false;   // COCR_NO_CONV_MFMA=1: the all-VALU fp32 frontend conv kernel also in bf16 mode (A/B)
     bool no_dw_fuse = false;     // COCR_NO_DW_FUSE=1: depthwise conv as its own launch (A/B)
     int chain_rows = 0;          // rows per workgroup of the row-chain kernels (cocr_set_chain_rows / COCR_CHAIN_ROWS); 0 = by the number of rows
@@ -232,6 +233,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_DW_FUSE"); m->no_dw_fuse = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_CONV_MFMA"); m->no_conv_mfma = e && e[0] == '1'; }
     { const char *e = getenv("COCR_NO_FRONT96"); m->no_front96 = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_NO_FRONT32"); m->no_front32 = e && e[0] == '1'; }
     { const char *e = getenv("COCR_BEAM_REF"); m->beam_ref = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_STAMPS"); if (e && e[0] == '1') { (void)hipHostMalloc((void **)&m->stamps, 4096 * 8); memset(m->stamps, 0, 4096 * 8); } }
     int f = hp->height;
@@ -941,6 +943,23 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                            F32(P.w0), F32(P.b0), zb);
         LAUNCH_CHECK();
     } else if (!front_fused) {
+    bool pw_fused = false;
+    if constexpr (sizeof(T) == 2) {
+        // 32 conv channels (the reference's default model): conv.0 + ReLU + depthwise conv.2 + pointwise conv.3 + ReLU in one launch
+        // (conv.hip.h: frontend_conv12pw32_kernel); with debug taps the separate kernels run (Z2 exists there; same arithmetic)
+        if (C == 32 && F2 <= 32 && !m->debug && !m->no_front32) {
+            ProfScope ps(m, s, FAM_CONV12);
+            const int HS = (H + 11) & ~3;
+            const size_t lds = (size_t)(4 * 16 + 3) * HS * 4 + (size_t)16 * F2 * 80;
+            auto kern = frontend_conv12pw32_kernel<TIn>;
+            GEMM_TRY(raise_lds_limit((const void *)kern, lds));
+            hipLaunchKernelGGL(kern, dim3(ceil_div(T2, 16), N), dim3(256), lds, s, lines, H, W, T1, F1, T2, F2, F32(P.w0), F32(P.b0),
+                               F32(P.stages[0].dw_w), F32(P.stages[0].dw_b), (const bf16_t *)WT(P.stages[0].pw_w), F32(P.stages[0].pw_b), (bf16_t *)zb);
+            LAUNCH_CHECK();
+            pw_fused = true;
+        }
+    }
+    if (!pw_fused) {
     {
         ProfScope ps(m, s, FAM_CONV12);
         bool done = false;
@@ -964,6 +983,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         ProfScope ps(m, s, FAM_FPW);
         EpiBiasAct<T, ACT_RELU> epi{zb, C, F32(P.stages[0].pw_b), C};
         GEMM_TRY(launch_gemm<T>(s, za, C, WT(P.stages[0].pw_w), C, N * T2 * F2, C, C, epi));
+    }
     }
     }
     if (!f2only && (rc = tap<T>(m, s, "front.z3", zb, (size_t)N * T2 * F2 * C))) return rc;

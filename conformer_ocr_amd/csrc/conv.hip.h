@@ -124,6 +124,115 @@ __global__ __launch_bounds__(256) void frontend_conv12_kernel(const TIn *__restr
     }
 }
 
+typedef unsigned u32x2_conv __attribute__((ext_vector_type(2)));
+// bf16(max(v, 0)) of four values as two packed registers
+__device__ __forceinline__ u32x2_conv relu_pack4(const f32x4 &v) {
+    const bf16x2 lo = {(bf16_t)fmaxf(v[0], 0.0f), (bf16_t)fmaxf(v[1], 0.0f)}, hi = {(bf16_t)fmaxf(v[2], 0.0f), (bf16_t)fmaxf(v[3], 0.0f)};
+    return (u32x2_conv){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
+
+// ---- frontend F1+F2+F3 for 32 conv channels (the reference's default model, default_specs.py:48-61), bf16 mode (round 4) --------------
+// frontend_conv12_kernel's walk (16 frames x 16 channel pairs per workgroup) with the pointwise Conv2d(32,32,1) + ReLU
+// (convolution.py:203-205) behind it in the same launch: the workgroup's Z2 rows (16 F positions x 32 channels, bf16 -- the rounding
+// point the separate GEMM had) stay in LDS and are the B operands of one v_mfma_f32_16x16x32_bf16 per (16 positions, 16 output channels)
+// -- K = 32 is a single k-chunk --, the Z3 rows leave through the same tile as whole 64-byte rows.  Replaces two whole-chip launches
+// (35.6 us + a 23 us GEMM that read and wrote 14.7 MB each at 1.3 TB/s) by one; Z2 never exists in memory.
+template <typename TIn>
+__global__ __launch_bounds__(256) void frontend_conv12pw32_kernel(const TIn *__restrict__ X, int H, int W, int T1, int F1, int Tn, int F,
+                                                                  const float *__restrict__ w0, const float *__restrict__ b0,
+                                                                  const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                  const bf16_t *__restrict__ wpw, const float *__restrict__ bpw, bf16_t *__restrict__ Z3) {
+    typedef bf16_t T;
+    constexpr int C = 32, TB = 16, C2 = C / 2, ZP = 80;          // ZP: bytes per Z2 row in LDS (64 + 16: the fragment reads of 16 rows spread over the banks)
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [ncols][HS]: LDS row rr <-> image row rr - 1, zero borders
+    const int b = blockIdx.y, t0 = blockIdx.x * TB;
+    const int ncols = 4 * TB + 3, HS = (H + 11) & ~3;
+    unsigned char *z2s = reinterpret_cast<unsigned char *>(xs + ncols * HS);      // [TB * F][ZP]
+    const int col0 = 4 * t0 - 3;
+    const TIn *Xb = X + (size_t)b * H * W;
+    for (int i = threadIdx.x; i < ncols * HS; i += 256) {
+        const int ci = i / HS, rr = i - ci * HS;
+        const int w = min(max(col0 + ci, 0), W - 1), r = min(max(rr - 1, 0), H - 1);
+        const float v = pixel_to_f32<TIn>(Xb[(size_t)r * W + w]);
+        xs[i] = (col0 + ci >= 0 && col0 + ci < W && rr >= 1 && rr <= H) ? v : 0.0f;
+    }
+    __syncthreads();
+    {
+        const int tl = threadIdx.x / C2, c = 2 * (threadIdx.x - tl * C2);
+        const int t = t0 + tl;
+        f32x2 k0[9], k2[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { k0[i] = (f32x2){w0[c * 9 + i], w0[(c + 1) * 9 + i]}; k2[i] = (f32x2){w2[c * 9 + i], w2[(c + 1) * 9 + i]}; }
+        const f32x2 bias0 = {b0[c], b0[c + 1]}, bias2 = {b2[c], b2[c + 1]};
+        const float *xc = xs + (4 * tl) * HS;
+        f32x4 cur[7], nxt[7];
+#pragma unroll
+        for (int ci = 0; ci < 7; ++ci) cur[ci] = *reinterpret_cast<const f32x4 *>(xc + ci * HS);
+        const bool tv[3] = {2 * t - 1 >= 0 && 2 * t - 1 < T1, 2 * t < T1, 2 * t + 1 < T1};
+        const f32x2 zero2 = {0.f, 0.f};
+        f32x2 prev[3] = {zero2, zero2, zero2};
+        unsigned char *out = z2s + (size_t)(tl * F) * ZP + c * 2;
+        for (int f = 0; f < F; ++f) {                          // (same arithmetic, in the same order, as frontend_conv12_kernel)
+#pragma unroll
+            for (int ci = 0; ci < 7; ++ci) nxt[ci] = *reinterpret_cast<const f32x4 *>(xc + ci * HS + 4 * (f + 1));
+            f32x2 s = bias2;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                f32x2 m = bias0, n = bias0;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    const f32x4 x0 = cur[2 * a + dt];
+                    const float x4 = nxt[2 * a + dt][0];
+                    m += k0[dt * 3 + 0] * (f32x2){x0[0], x0[0]} + k0[dt * 3 + 1] * (f32x2){x0[1], x0[1]} + k0[dt * 3 + 2] * (f32x2){x0[2], x0[2]};
+                    n += k0[dt * 3 + 0] * (f32x2){x0[2], x0[2]} + k0[dt * 3 + 1] * (f32x2){x0[3], x0[3]} + k0[dt * 3 + 2] * (f32x2){x4, x4};
+                }
+                const bool vm = tv[a] && 2 * f < F1, vn = tv[a] && 2 * f + 1 < F1;
+                m = vm ? (f32x2){fmaxf(m[0], 0.0f), fmaxf(m[1], 0.0f)} : zero2;
+                n = vn ? (f32x2){fmaxf(n[0], 0.0f), fmaxf(n[1], 0.0f)} : zero2;
+                s += k2[a * 3 + 0] * prev[a] + k2[a * 3 + 1] * m + k2[a * 3 + 2] * n;
+                prev[a] = n;
+            }
+            *reinterpret_cast<bf16x2 *>(out + (size_t)f * ZP) = (bf16x2){(T)s[0], (T)s[1]};      // (frames beyond T: finite values nobody stores)
+#pragma unroll
+            for (int ci = 0; ci < 7; ++ci) cur[ci] = nxt[ci];
+        }
+    }
+    __syncthreads();
+    // ---- pointwise conv + bias + ReLU: position tiles wave, wave + 4, ...; weights on the MFMA row side (a lane ends up with 4 consecutive
+    // output channels of one position)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const int ntile = TB * F / 16;
+    const bf16x8 wf0 = load_frag(wpw + (size_t)r16 * C + 8 * g), wf1 = load_frag(wpw + (size_t)(16 + r16) * C + 8 * g);
+    const f32x4 bp0 = *reinterpret_cast<const f32x4 *>(bpw + 4 * g), bp1 = *reinterpret_cast<const f32x4 *>(bpw + 16 + 4 * g);
+    constexpr int MAXT = 8;                                     // position tiles per wave at most (TB F / 64: F <= 32)
+    u32x2_conv o0[MAXT], o1[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int i = wave + 4 * u;
+        if (i < ntile) {
+            const bf16x8 za = *reinterpret_cast<const bf16x8 *>(z2s + (size_t)(16 * i + r16) * ZP + 16 * g);
+            const f32x4 a0 = mma16(wf0, za, bp0), a1 = mma16(wf1, za, bp1);
+            o0[u] = relu_pack4(a0);
+            o1[u] = relu_pack4(a1);
+        }
+    }
+    __syncthreads();                                            // every wave has read its Z2 fragments: the tile takes the Z3 rows (dense 64-byte rows)
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int i = wave + 4 * u;
+        if (i < ntile) {
+            *reinterpret_cast<u32x2_conv *>(z2s + (size_t)(16 * i + r16) * 64 + 8 * g) = o0[u];
+            *reinterpret_cast<u32x2_conv *>(z2s + (size_t)(16 * i + r16) * 64 + 32 + 8 * g) = o1[u];
+        }
+    }
+    __syncthreads();
+    // the workgroup's rows (frames t0 .. t0 + 15 of line b, F rows each) are consecutive rows of the (B T F, C) output
+    const int nvalid = min(TB, Tn - t0) * F;                    // rows of frames that exist
+    bf16_t *dst = Z3 + ((size_t)b * Tn + t0) * F * C;
+    for (int id = threadIdx.x; id < nvalid * 4; id += 256)
+        *reinterpret_cast<bf16x8 *>(dst + (size_t)id * 8) = *reinterpret_cast<const bf16x8 *>(z2s + (size_t)id * 16);
+}
+
 // ---- frontend F1+F2, bf16 mode, C % 64 == 0: the first conv on the matrix cores ------------------------------
 // Z1 = relu(conv 3x3 s2 of the 1-channel line) is a (pixels x 9) x (9 x C) product: K padded to 16 as k = 4 dt + df
 // (df = 3 and dt = 3 carry zero weights), so a lane's 4 k-values are 4 CONSECUTIVE image rows of one image column --
