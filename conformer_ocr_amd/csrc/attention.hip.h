@@ -533,42 +533,34 @@ constexpr int AF_SROWS = 32;                       // rows of a wave's shift til
 constexpr size_t AF_LDS = (size_t)(2 * AF_TK + 16 * AF_QT + AF_TK) * 128 + AF_WAVES * AF_SROWS * AF_SK * sizeof(float);
 static_assert(AF_LDS <= 160 * 1024, "LDS of the resident attention kernel");
 
+// A wave's state across the key passes: the query operands of its (at most two) tiles, their output accumulators, denominators and running
+// references
+struct AttnFullState {
+    bf16x8 qu[2][2], qv[2][2];
+    f32x4 o[2][4], osum[2];
+    float m_run[2];
+};
+
+// One key pass: the keys [kg0, kg0 + Tk) of the line are resident in LDS as local rows [0, Tk) (Tk a multiple of 64; kg0 = 0 in the first
+// -- for lines of at most 320 frames the only -- pass)
 template <int NT>
 __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const unsigned char *vs, const unsigned char *ps, float *sk,
-                                                const bf16x8 (&qq)[2][2], const f32x4 (&u4)[2][2], const f32x4 (&v4)[2][2], bf16_t *ctxh, int ctx_stride,
-                                                int i_first, int lb_first, int Tn, int Tk, float scale, int lane) {
+                                                AttnFullState &st, int lb_first, int Tn, int Tk, int kg0, int lane) {
     typedef bf16_t T;
     constexpr int KC = 2, DT = 4, RS = 128;
     const int il = lane & 15, g = lane >> 4;
     const int fo0 = ((g ^ (il & 7)) << 4), fo1 = (((4 + g) ^ (il & 7)) << 4);        // byte offset of this lane's 16 bytes of k-chunk 0 / 1 in a row = il mod 8
-    // ---- query operands: (q + u) scale and (q + v) scale of this lane's query in each tile
-    bf16x8 qu[NT][KC], qv[NT][KC];
-    {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int c = 0; c < KC; ++c)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = (float)qq[t][c][j];
-                    qu[t][c][j] = (T)((x + u4[c][j >> 2][j & 3]) * scale);
-                    qv[t][c][j] = (T)((x + v4[c][j >> 2][j & 3]) * scale);
-                }
-    }
-    f32x4 o[NT][DT], osum[NT];
-    float m_run[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        osum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        m_run[t] = 0.f;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) o[t][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    auto &qu = st.qu;
+    auto &qv = st.qv;
+    auto &o = st.o;
+    auto &osum = st.osum;
+    auto &m_run = st.m_run;
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = il == 0 ? (T)1.0f : (T)0.0f;
 
     for (int j0 = 0; j0 < Tk; j0 += 64) {
+        const bool first_tile = kg0 + j0 == 0;                                // the line's first key tile sets the running references
         f32x4 sc[NT][4], keep[NT];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -650,7 +642,7 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
             m = max3_f(m, sc[t][3][1], sc[t][3][2]);
             tmax[t] = max3_f(m, sc[t][3][3], sc[t][3][3]);
         }
-        if (j0 + 64 > Tn) {                                                  // uniform: only the last tile has keys beyond T
+        if (kg0 + j0 + 64 > Tn) {                                            // uniform: only the line's last tile has keys beyond T
             asm volatile("; keys beyond the line" ::: "memory");
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -659,7 +651,7 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (j0 + 16 * tt + 4 * g + r >= Tn) sc[t][tt][r] = -INFINITY;
+                        if (kg0 + j0 + 16 * tt + 4 * g + r >= Tn) sc[t][tt][r] = -INFINITY;
                         m = fmaxf(m, sc[t][tt][r]);
                     }
                 tmax[t] = m;
@@ -672,15 +664,15 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
         // Lazy rescaling, per query tile exactly as in the tiled kernel (the reference of a tile moves only when one of ITS queries exceeds it
         // by more than LAZY; the first key tile sets it) -- a tile whose reference stays gets delta = 0, alpha = 2^-0 = 1: the same bits
         constexpr float LAZY = 8.0f;
-        bool need[NT], any = j0 == 0;
+        bool need[NT], any = first_tile;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { need[t] = j0 == 0 || __builtin_amdgcn_ballot_w64(tmax[t] > LAZY) != 0; any = any || need[t]; }
+        for (int t = 0; t < NT; ++t) { need[t] = first_tile || __builtin_amdgcn_ballot_w64(tmax[t] > LAZY) != 0; any = any || need[t]; }
         if (any) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float delta = j0 == 0 ? tmax[t] : (need[t] ? fmaxf(tmax[t], 0.f) : 0.f);
-                const float alpha = j0 == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-                m_run[t] = j0 == 0 ? tmax[t] : m_run[t] + delta;
+                const float delta = first_tile ? tmax[t] : (need[t] ? fmaxf(tmax[t], 0.f) : 0.f);
+                const float alpha = first_tile ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run[t] = first_tile ? tmax[t] : m_run[t] + delta;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) osum[t][r] *= alpha;
 #pragma unroll
@@ -713,7 +705,16 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
             }
         }
     }
-    // ---- normalise and store: whole 128-byte rows through the wave's shift tile, as in the tiled kernel
+}
+
+// normalise and store: whole 128-byte rows through the wave's shift tile, as in the tiled kernel
+template <int NT>
+__device__ __forceinline__ void attn_full_store(float *sk, const AttnFullState &st, bf16_t *ctxh, int ctx_stride, int i_first, int Tn, int lane) {
+    typedef bf16_t T;
+    constexpr int DT = 4;
+    const int il = lane & 15, g = lane >> 4;
+    auto &o = st.o;
+    auto &osum = st.osum;
     unsigned char *stg = reinterpret_cast<unsigned char *>(sk);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -735,15 +736,21 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
     }
 }
 
+// `kpass`: keys resident per pass (a multiple of 64, at most AF_TK).  Lines of at most kpass frames take one pass (the form described above);
+// longer lines (round 4: the wide model's bucketed widths, up to 600 frames and beyond) walk their keys in passes of kpass -- K, V and the
+// band of the next pass replace the previous ones between two barriers, the waves' softmax state (AttnFullState) carries over.  Per 320 keys
+// and 160 queries a pass stages 143 KB once; the tiled kernel stages 24 KB per (64 keys, 64 queries) = 300 KB for the same pairs, behind two
+// barriers per key tile.
 __global__ __launch_bounds__(64 * AF_WAVES) void relpos_attention_full_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k, const bf16_t *__restrict__ v,
                                                                     const bf16_t *__restrict__ ptab, const float *__restrict__ ub,
                                                                     const float *__restrict__ vb, bf16_t *__restrict__ ctx,
-                                                                    int Tn, int Tp, int heads, float scale, int pos_center, int ntw) {
+                                                                    int Tn, int Tp, int heads, float scale, int pos_center, int ntw, int kpass) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
-    const int Tk = (Tn + 63) & ~63;                    // keys walked (rows of K / V staged): whole 64-key tiles; rows beyond T are zero in q / k / v
-    const int nbr = 16 * ntw + Tk;                     // band rows this workgroup can touch
-    unsigned char *ks = att_smem, *vs = ks + (size_t)Tk * 128, *ps = vs + (size_t)Tk * 128;
+    const int Tk = (Tn + 63) & ~63;                    // keys walked: whole 64-key tiles; rows beyond T are zero in q / k / v
+    const int Kp = min(kpass, Tk);                     // keys of a full pass (rows of K / V staged)
+    const int nbr = 16 * ntw + Kp;                     // band rows this workgroup can touch in one pass
+    unsigned char *ks = att_smem, *vs = ks + (size_t)Kp * 128, *ps = vs + (size_t)Kp * 128;
     float *skew = reinterpret_cast<float *>(ps + (size_t)nbr * 128);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -778,27 +785,54 @@ __global__ __launch_bounds__(64 * AF_WAVES) void relpos_attention_full_kernel(co
                 v4[c][hlf] = *reinterpret_cast<const f32x4 *>(vb + hh * 64 + c * 32 + 8 * g + 4 * hlf);
             }
     }
-    // ---- K, V and the band -> LDS by DMA: one wave-instruction = 8 rows of 128 bytes; chunk c of row r lands at chunk c ^ (r & 7)
-    {
+    // ---- K, V and the band of the keys [kg0, kg0 + kn) -> LDS by DMA: one wave-instruction = 8 rows of 128 bytes; chunk c of row r lands at
+    // chunk c ^ (r & 7).  Band geometry: local band row lr <-> table row (pos_center - i0 - qmax + kg0) + lr, qmax = 16 ntw - 1.
+    auto stage = [&](int kg0, int kn) {
         const int r8 = lane >> 3, cs = lane & 7, gch = (cs ^ r8) * 8;       // this lane's row inside a group of 8 and the GLOBAL chunk it fetches
-        const T *kb = k + (size_t)bh * Tp * 64, *vbs = v + (size_t)bh * Tp * 64;
-        for (int rg = wave; rg < Tk / 8; rg += AF_WAVES) {
+        const T *kb = k + ((size_t)bh * Tp + kg0) * 64, *vbs = v + ((size_t)bh * Tp + kg0) * 64;
+        for (int rg = wave; rg < kn / 8; rg += AF_WAVES) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(ks + rg * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vbs + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(vs + rg * 1024), 16, 0, 0);
         }
         const int prow = heads * 64;
-        const T *pb = ptab + (size_t)(pos_center - i0 - (16 * ntw - 1)) * prow + hh * 64;
-        for (int rg = wave; rg < nbr / 8; rg += AF_WAVES)
+        const T *pb = ptab + (size_t)(pos_center - i0 - (16 * ntw - 1) + kg0) * prow + hh * 64;
+        for (int rg = wave; rg < (16 * ntw + kn) / 8; rg += AF_WAVES)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + (size_t)(rg * 8 + r8) * prow + gch), (lds_ptr_t)(ps + rg * 1024), 16, 0, 0);
+    };
+    stage(0, Kp);
+    // ---- query operands: (q + u) scale and (q + v) scale of this lane's query in each tile; empty accumulators
+    AttnFullState st;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = (float)qq[t][c][j];
+                st.qu[t][c][j] = (T)((x + u4[c][j >> 2][j & 3]) * scale);
+                st.qv[t][c][j] = (T)((x + v4[c][j >> 2][j & 3]) * scale);
+            }
+        st.osum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        st.m_run[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) st.o[t][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (mine == 0) return;
-    const int lb_first = 16 * ntw - 16 - 16 * first;   // band row of R^T row 0 for the first tile and key 0; tile t: 16 t lower; keys from js: + js
-    T *ctxh = ctx + (size_t)b * Tn * (heads * 64) + hh * 64;
+    const int lb_first = 16 * ntw - 16 - 16 * first;   // band row of R^T row 0 for the first tile and the pass's key 0; tile t: 16 t lower; keys from js: + js
     float *sk = skew + wave * AF_SROWS * AF_SK;
-    if (mine == 1) attn_full_tiles<1>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
-    else attn_full_tiles<2>(ks, vs, ps, sk, qq, u4, v4, ctxh, heads * 64, i_first, lb_first, Tn, Tk, scale, lane);
+    for (int kg0 = 0; kg0 < Tk; kg0 += Kp) {
+        const int kn = min(Kp, Tk - kg0);
+        if (kg0 > 0) {
+            __builtin_amdgcn_s_barrier();              // every wave is done with the previous pass's rows
+            stage(kg0, kn);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (mine == 1) attn_full_tiles<1>(ks, vs, ps, sk, st, lb_first, Tn, kn, kg0, lane);
+        else if (mine == 2) attn_full_tiles<2>(ks, vs, ps, sk, st, lb_first, Tn, kn, kg0, lane);
+    }
+    T *ctxh = ctx + (size_t)b * Tn * (heads * 64) + hh * 64;
+    if (mine == 1) attn_full_store<1>(sk, st, ctxh, heads * 64, i_first, Tn, lane);
+    else if (mine == 2) attn_full_store<2>(sk, st, ctxh, heads * 64, i_first, Tn, lane);
 }
 
 template <typename T, int DHP> static inline size_t attention_lds_bytes() {

@@ -165,6 +165,7 @@ struct cocr_model {
     bool no_front_chain = false; // COCR_NO_FRONT_CHAIN=1: the frontend's output linear as a split-K GEMM + reduction in front of the first chain launch (A/B)
     bool ffn_probe = false;      // COCR_FFN_PROBE=1: one extra FFN-only row-chain launch per forward (measurement; results discarded)
     int att_resident_min = 192;  // COCR_ATT_RESIDENT_MIN: fewest workgroups for which the LDS-resident attention kernel is chosen (tests: 1)
+    bool att_resident_long = false;   // COCR_ATT_RESIDENT_LONG=1: the LDS-resident attention kernel also for lines of more than 320 frames (key passes; A/B)
     bool att_tiled = false;      // COCR_ATT_TILED=1: the tiled attention kernel also for lines of <= 320 frames (A/B against the LDS-resident one)
     bool no_kskip = false;       // COCR_NO_KSKIP=1: zero-padded narrow models multiply their zero k-steps too (A/B)
     bool chain_xcd = true;       // COCR_CHAIN_XCD=0: row blocks in plain workgroup order (A/B)
@@ -226,6 +227,7 @@ extern "C" int cocr_create(const cocr_hparams *hp, int device, cocr_model **out)
     { const char *e = getenv("COCR_NO_FRONT_CHAIN"); m->no_front_chain = e && e[0] == '1'; }
     { const char *e = getenv("COCR_FFN_PROBE"); m->ffn_probe = e && e[0] == '1'; }
     { const char *e = getenv("COCR_ATT_TILED"); m->att_tiled = e && e[0] == '1'; }
+    { const char *e = getenv("COCR_ATT_RESIDENT_LONG"); m->att_resident_long = e && e[0] == '1'; }
     { const char *e = getenv("COCR_CHAIN_XCD"); if (e) m->chain_xcd = e[0] != '0'; }
     { const char *e = getenv("COCR_NO_KSKIP"); m->no_kskip = e && e[0] == '1'; }
     { const char *e = getenv("COCR_ATT_RESIDENT_MIN"); if (e) m->att_resident_min = atoi(e); }
@@ -876,19 +878,24 @@ extern "C" int cocr_profile_read(cocr_model *m, char *names, size_t names_len, d
 template <typename T, int DHP>
 static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k, const T *v, const T *ptab, const float *ub,
                                    const float *vb, T *ctx, int Tn, int Tp, int heads, int dh, float scale, int pos_center, unsigned long long *stamps = nullptr,
-                                   bool tiled_only = false, int resident_min = 192) {
+                                   bool tiled_only = false, int resident_min = 192, bool resident_long = false) {
     if constexpr (sizeof(T) == 2 && DHP == 64) {
         // lines of at most 320 frames (the metric's: 300): K, V and the band of a (line, head) resident in LDS, no barriers in the key loop
         // ... when there are enough (line, head) pairs to give most CUs one of its workgroups: a small batch is served faster by the tiled
         // kernel's five workgroups per (line, head) on CUs of their own (B = 1: 0.83 ms per forward with this kernel against 0.76 ms)
         const int ntiles = ceil_div(Tn, 16), nqb = ceil_div(ntiles, AF_QT);
-        if (dh == DHP && Tn <= AF_TK && !tiled_only && !stamps && nqb * N * heads >= resident_min) {
-            const int ntw = ceil_div(ntiles, nqb), Tk = round_up(Tn, 64);
+        // Longer lines (`resident_long`, COCR_ATT_RESIDENT_LONG=1: measured, not the default) walk their keys in passes of at most AF_TK: at the wide
+        // model's 600-frame lines the tiled kernel is the faster one (83 us against 91 us per launch of 32 lines x 8 heads: its staging is
+        // amortised over ten key tiles there and three of its workgroups share a CU; 4.6 k against 4.2 k query-key pairs per us and CU).
+        if (dh == DHP && (Tn <= AF_TK || resident_long) && !tiled_only && !stamps && nqb * N * heads >= resident_min) {
+            // (lines of more than AF_TK frames: their keys in passes of at most AF_TK, balanced -- 600 frames = 2 x 320, 700 = 3 x 256)
+            const int Tk0 = round_up(Tn, 64), npass = ceil_div(Tk0, AF_TK), Tk = round_up(ceil_div(Tk0, npass), 64);
+            const int ntw = ceil_div(ntiles, nqb);
             const size_t lds = (size_t)(2 * Tk + 16 * ntw + Tk) * 128 + AF_WAVES * AF_SROWS * AF_SK * sizeof(float);
             hipError_t e = raise_lds_limit((const void *)relpos_attention_full_kernel, lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(relpos_attention_full_kernel, dim3(nqb, N * heads), dim3(64 * AF_WAVES), lds, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
-                               (const bf16_t *)ptab, ub, vb, (bf16_t *)ctx, Tn, Tp, heads, scale * 1.44269504088896340736f, pos_center, ntw);
+                               (const bf16_t *)ptab, ub, vb, (bf16_t *)ctx, Tn, Tp, heads, scale * 1.44269504088896340736f, pos_center, ntw, Tk);
             return hipGetLastError();
         }
     }
@@ -1178,7 +1185,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
                 const LayerW &w = P.layers[l];
                 {
                     ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, (m->stamps && l == 5) ? m->stamps + 192 : nullptr, m->att_tiled, m->att_resident_min)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, (m->stamps && l == 5) ? m->stamps + 192 : nullptr, m->att_tiled, m->att_resident_min, m->att_resident_long)))
                     if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
                 }
@@ -1240,7 +1247,7 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
         { ProfScope ps(m, s, FAM_QKV); EpiQKV<T> e{q, k, v, F32(w.bqkv), D, dh, dhp, heads, Tn, Tp, 3 * D}; GEMM_TRY(launch_gemm<T>(s, xn, D, WT(w.wqkv), D, M, 3 * D, D, e)); }
         {
             ProfScope ps(m, s, FAM_ATTN);
-#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, nullptr, m->att_tiled, m->att_resident_min)))
+#define ATTN(DHP) GEMM_TRY((launch_attention<T, DHP>(s, N, q, k, v, (const T *)(m->ptab + (size_t)l * m->ptab_stride), F32(w.ub), F32(w.vb), ctx, Tn, Tp, heads, dh, scale, m->pos_maxlen - 1, nullptr, m->att_tiled, m->att_resident_min, m->att_resident_long)))
             if (dhp == 32) ATTN(32); else if (dhp == 64) ATTN(64); else if (dhp == 96) ATTN(96); else ATTN(128);
 #undef ATTN
         }

@@ -308,18 +308,23 @@ def test_bucketed_loop_on_the_wide_model(text_case):
     assert f"{rep['chars']}\tCharacters" in rep['report']
 
 
-@pytest.mark.parametrize('n,w', [(3, 40), (3, 68), (3, 132), (2, 300), (5, 640), (4, 648), (3, 1000), (17, 1200), (2, 1277), (32, 1200), (64, 300)])
+@pytest.mark.parametrize('n,w', [(3, 40), (3, 68), (3, 132), (2, 300), (5, 640), (4, 648), (3, 1000), (17, 1200), (2, 1277), (32, 1200), (64, 300),
+                                 (3, 1300), (2, 2400), (2, 2810), (1, 5000), (12, 2400)])
 def test_lds_resident_attention_equals_the_tiled_kernel_bit_for_bit(n, w, monkeypatch):
     """Lines of at most 320 output frames, in batches of at least 192 workgroups (24 lines x 4 heads x 2), run `relpos_attention_full_kernel` (K, V and the positional band of a (line, head) resident in LDS,
     2 - 3 query tiles per wave, no barriers in the key loop); COCR_ATT_TILED=1 keeps the tiled kernel.  Same products, same shift, the same
     lazy-rescaling decisions per query tile: the logits of two blocks must be IDENTICAL, on ragged batches from 10 to 320 frames, and
-    identical from run to run (the first version read matrix results in inline assembly too early: last-bit noise from run to run)."""
+    identical from run to run (the first version read matrix results in inline assembly too early: last-bit noise from run to run).
+    Round 4: two waves per SIMD with at most two query tiles each, and lines of MORE than 320 frames in key passes (325 frames = 2 x 192
+    keys, 600 = 2 x 320, 703 = 3 x 256, 1250 = 4 x 320: K / V / band restaged between two barriers, the softmax state carried over; behind
+    COCR_ATT_RESIDENT_LONG=1 -- at those lengths the tiled kernel is the faster one and stays the default)."""
     hp = synth.hparams('cfg2', num_encoder_layers=2)
     state = synth.make_state_dict(hp, seed=3, decoder_gain=1.0, style='text')
     image, lens = synth.make_lines(n, hp.height, w, seed=5, widths=[max(33, w - 37 * i) for i in range(n)])
     x = torch.from_numpy(image[:, 0]).cuda()
     if n < 32:
-        monkeypatch.setenv('COCR_ATT_RESIDENT_MIN', '1')       # (by itself the library picks the resident kernel from 192 workgroups on: the last two cases)
+        monkeypatch.setenv('COCR_ATT_RESIDENT_MIN', '1')       # (by itself the library picks the resident kernel from 192 workgroups on: the last two of the first row)
+    monkeypatch.setenv('COCR_ATT_RESIDENT_LONG', '1')         # (and for lines of at most 320 frames: the second row's cases are an A/B switch)       # (by itself the library picks the resident kernel from 192 workgroups on: the last two cases)
     eng = make_engine(hp, state, 'bf16')
     runs = [eng.forward(x, lens)[0].cpu().numpy().copy() for _ in range(3)]
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
