@@ -528,6 +528,9 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
 constexpr int AF_QT = 10;                          // query tiles (16 queries) per workgroup at most
 constexpr int AF_TK = 320;                         // keys resident at most
 constexpr int AF_SK = 20;                          // row stride (floats) of a wave's shift tile
+#ifndef COCR_AF_TWOPART
+#define COCR_AF_TWOPART 1       // dev: 0 = the first pass staged in one part
+#endif
 constexpr int AF_WAVES = 8;                        // waves per workgroup: two per SIMD (round 4; the first form had one per SIMD with up to three query tiles)
 constexpr int AF_SROWS = 32;                       // rows of a wave's shift tile (the 48 band rows of a step go through it in two overlapping rounds)
 constexpr size_t AF_LDS = (size_t)(2 * AF_TK + 16 * AF_QT + AF_TK) * 128 + AF_WAVES * AF_SROWS * AF_SK * sizeof(float);
@@ -545,7 +548,7 @@ struct AttnFullState {
 // -- for lines of at most 320 frames the only -- pass)
 template <int NT>
 __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const unsigned char *vs, const unsigned char *ps, float *sk,
-                                                AttnFullState &st, int lb_first, int Tn, int Tk, int kg0, int lane) {
+                                                AttnFullState &st, int lb_first, int Tn, int Tk, int kg0, int lane, bool sync_after_first = false) {
     typedef bf16_t T;
     constexpr int KC = 2, DT = 4, RS = 128;
     const int il = lane & 15, g = lane >> 4;
@@ -704,6 +707,10 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
                 o[t][d] = mma16(v1, pb[t][1], o[t][d]);
             }
         }
+        if (j0 == 0 && sync_after_first) {             // (uniform) the rows behind the first key tile were requested while it was computed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 }
 
@@ -741,6 +748,7 @@ __device__ __forceinline__ void attn_full_store(float *sk, const AttnFullState &
 // band of the next pass replace the previous ones between two barriers, the waves' softmax state (AttnFullState) carries over.  Per 320 keys
 // and 160 queries a pass stages 143 KB once; the tiled kernel stages 24 KB per (64 keys, 64 queries) = 300 KB for the same pairs, behind two
 // barriers per key tile.
+template <bool LONG>
 __global__ __launch_bounds__(64 * AF_WAVES) void relpos_attention_full_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k, const bf16_t *__restrict__ v,
                                                                     const bf16_t *__restrict__ ptab, const float *__restrict__ ub,
                                                                     const float *__restrict__ vb, bf16_t *__restrict__ ctx,
@@ -787,19 +795,21 @@ __global__ __launch_bounds__(64 * AF_WAVES) void relpos_attention_full_kernel(co
     }
     // ---- K, V and the band of the keys [kg0, kg0 + kn) -> LDS by DMA: one wave-instruction = 8 rows of 128 bytes; chunk c of row r lands at
     // chunk c ^ (r & 7).  Band geometry: local band row lr <-> table row (pos_center - i0 - qmax + kg0) + lr, qmax = 16 ntw - 1.
-    auto stage = [&](int kg0, int kn) {
+    // `a` .. `b`: the local keys staged by this call (multiples of 64): K / V rows [a, b) and the band rows they add -- [0, 16 ntw + b) for
+    // a == 0, [16 ntw + a, 16 ntw + b) behind an earlier call
+    auto stage = [&](int kg0, int a, int b2) {
         const int r8 = lane >> 3, cs = lane & 7, gch = (cs ^ r8) * 8;       // this lane's row inside a group of 8 and the GLOBAL chunk it fetches
         const T *kb = k + ((size_t)bh * Tp + kg0) * 64, *vbs = v + ((size_t)bh * Tp + kg0) * 64;
-        for (int rg = wave; rg < kn / 8; rg += AF_WAVES) {
+        for (int rg = a / 8 + wave; rg < b2 / 8; rg += AF_WAVES) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(ks + rg * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vbs + (size_t)(rg * 8 + r8) * 64 + gch), (lds_ptr_t)(vs + rg * 1024), 16, 0, 0);
         }
         const int prow = heads * 64;
         const T *pb = ptab + (size_t)(pos_center - i0 - (16 * ntw - 1) + kg0) * prow + hh * 64;
-        for (int rg = wave; rg < (16 * ntw + kn) / 8; rg += AF_WAVES)
+        for (int rg = (a ? (16 * ntw + a) / 8 : 0) + wave; rg < (16 * ntw + b2) / 8; rg += AF_WAVES)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + (size_t)(rg * 8 + r8) * prow + gch), (lds_ptr_t)(ps + rg * 1024), 16, 0, 0);
     };
-    stage(0, Kp);
+    stage(0, 0, (!LONG && COCR_AF_TWOPART) ? min(64, Kp) : Kp);
     // ---- query operands: (q + u) scale and (q + v) scale of this lane's query in each tile; empty accumulators
     AttnFullState st;
 #pragma unroll
@@ -819,11 +829,29 @@ __global__ __launch_bounds__(64 * AF_WAVES) void relpos_attention_full_kernel(co
     }
     const int lb_first = 16 * ntw - 16 - 16 * first;   // band row of R^T row 0 for the first tile and the pass's key 0; tile t: 16 t lower; keys from js: + js
     float *sk = skew + wave * AF_SROWS * AF_SK;
+    if constexpr (!LONG) {
+        // one pass (lines of at most kpass frames; the measured shape).  Staged in two parts: the first key tile (K / V rows 0..63 and the
+        // 16 ntw + 64 band rows its scores touch: 44 of 143 KB at the metric's shape) is waited for and published alone, the rest is
+        // requested behind that barrier and lands while the tile is computed; a second barrier at the end of the first loop iteration
+        // (attn_full_tiles: sync_after_first) publishes it.  Waves without a query tile take part in both barriers and leave.
+        const bool two = COCR_AF_TWOPART && Kp > 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (two) stage(0, 64, Kp);
+        if (mine == 0) {
+            if (two) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+            return;
+        }
+        T *ctxh = ctx + (size_t)b * Tn * (heads * 64) + hh * 64;
+        if (mine == 1) { attn_full_tiles<1>(ks, vs, ps, sk, st, lb_first, Tn, Kp, 0, lane, two); attn_full_store<1>(sk, st, ctxh, heads * 64, i_first, Tn, lane); }
+        else { attn_full_tiles<2>(ks, vs, ps, sk, st, lb_first, Tn, Kp, 0, lane, two); attn_full_store<2>(sk, st, ctxh, heads * 64, i_first, Tn, lane); }
+        return;
+    }
     for (int kg0 = 0; kg0 < Tk; kg0 += Kp) {
         const int kn = min(Kp, Tk - kg0);
         if (kg0 > 0) {
             __builtin_amdgcn_s_barrier();              // every wave is done with the previous pass's rows
-            stage(kg0, kn);
+            stage(kg0, 0, kn);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

@@ -892,9 +892,10 @@ static hipError_t launch_attention(hipStream_t s, int N, const T *q, const T *k,
             const int Tk0 = round_up(Tn, 64), npass = ceil_div(Tk0, AF_TK), Tk = round_up(ceil_div(Tk0, npass), 64);
             const int ntw = ceil_div(ntiles, nqb);
             const size_t lds = (size_t)(2 * Tk + 16 * ntw + Tk) * 128 + AF_WAVES * AF_SROWS * AF_SK * sizeof(float);
-            hipError_t e = raise_lds_limit((const void *)relpos_attention_full_kernel, lds);
+            auto kern = npass > 1 ? relpos_attention_full_kernel<true> : relpos_attention_full_kernel<false>;
+            hipError_t e = raise_lds_limit((const void *)kern, lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(relpos_attention_full_kernel, dim3(nqb, N * heads), dim3(64 * AF_WAVES), lds, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+            hipLaunchKernelGGL(kern, dim3(nqb, N * heads), dim3(64 * AF_WAVES), lds, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
                                (const bf16_t *)ptab, ub, vb, (bf16_t *)ctx, Tn, Tp, heads, scale * 1.44269504088896340736f, pos_center, ntw, Tk);
             return hipGetLastError();
         }

@@ -16,7 +16,8 @@ hp = synth.hparams('cfg2')
 eng = HipRecognizer(hp, dev, 'bf16')
 eng.load_state(synth.make_state_dict(hp, seed=1236, decoder_gain=8.0))
 eng.finalize()
-img, lens = synth.make_lines(32, hp.height, 1200, seed=7)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+img, lens = synth.make_lines(N, hp.height, 1200, seed=7)
 x = torch.from_numpy(img[:, 0]).to(dev)
 for _ in range(3):
     eng.forward(x, lens.astype(np.int32))
