@@ -51,6 +51,30 @@ __global__ static void k_transpose(const float *__restrict__ in, float *__restri
     for (int j = ty; j < 32; j += 8)
         if (c0 + j < C && r0 + tx < ldo) out[(size_t)(c0 + j) * ldo + r0 + tx] = tile[tx][j];
 }
+// 'medium' matmul precision (round 4): ONE pass over an fp32 (R, C) matrix for everything its weight-gradient and input-gradient products
+// need -- outT (C, ldo) = its transpose in bf16, zero beyond row R (the operand of dW = dY^T X; the separate k_transpose + k_f32_to_bf16
+// wrote and re-read the fp32 transpose); outR (R, C) = its bf16 copy (the operand of dX = dY W), or null; part[tile row][C] = the column sums
+// of each 32-row tile, rows added in order (the bias gradient's partial sums: k_colsum_final adds the tiles in a fixed order), or null.
+__global__ __launch_bounds__(256) static void k_transpose_bf16(const float *__restrict__ in, bf16_t *__restrict__ outT, bf16_t *__restrict__ outR,
+                                                              float *__restrict__ part, int R, int C, int ldo) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const bool ok = r0 + j < R && c0 + tx < C;
+        const float v = ok ? in[(size_t)(r0 + j) * C + c0 + tx] : 0.f;
+        tile[j][tx] = v;
+        if (outR && ok) outR[(size_t)(r0 + j) * C + c0 + tx] = (bf16_t)v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < ldo) outT[(size_t)(c0 + j) * ldo + r0 + tx] = (bf16_t)tile[tx][j];
+    if (part && ty == 0 && c0 + tx < C && r0 < R) {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sum += tile[j][tx];
+        part[(size_t)blockIdx.y * C + c0 + tx] = sum;
+    }
+}
 // out (M, ldo) <- in (M, C), columns C..ldo-1 zero
 __global__ static void k_pad_cols(const float *__restrict__ in, float *__restrict__ out, int M, int C, int ldo) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * ldo; i += (size_t)gridDim.x * blockDim.x) {
