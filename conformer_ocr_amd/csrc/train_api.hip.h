@@ -24,12 +24,14 @@ struct TrainState {
     float *pe = nullptr;                      // sinusoid rows for relative positions T-1 ... -(T-1), (2T-1, D)
     int peT = 0;
     bool matmul_bf16 = false;                 // cocr_train_set_matmul: the Linear / pointwise-conv products on bf16-rounded operands (fp32 accumulate)
+    unsigned char *Wb = nullptr, *WTb = nullptr;   // 'medium': bf16 copies of every Linear weight (N, K) and of its transpose (K, N), written by the forward, read by the
+                                              // backward (byte offset of a tensor = its float offset x 4: 16-byte aligned like the fp32 tensors)
 };
 
 static void train_free(cocr_model *m) {
     TrainState *t = m->train;
     if (!t) return;
-    for (void *p : {(void *)t->P, (void *)t->G, (void *)t->Mo, (void *)t->Vo, (void *)t->ws, (void *)t->pe})
+    for (void *p : {(void *)t->P, (void *)t->G, (void *)t->Mo, (void *)t->Vo, (void *)t->ws, (void *)t->pe, (void *)t->Wb, (void *)t->WTb})
         if (p) (void)hipFree(p);
     delete t;
     m->train = nullptr;
@@ -40,7 +42,13 @@ static bool train_is_buffer(const std::string &n) { return n.find("running_mean"
 extern "C" int cocr_train_set_matmul(cocr_model *m, int bf16_operands) {
     if (!m) return fail(COCR_EINVAL, "null argument");
     if (!m->train) return fail(COCR_ESTATE, "cocr_train_begin first");
-    m->train->matmul_bf16 = bf16_operands != 0;
+    TrainState *t = m->train;
+    t->matmul_bf16 = bf16_operands != 0;
+    if (t->matmul_bf16 && !t->Wb) {
+        HIP_TRY(hipSetDevice(m->device));
+        HIP_TRY(hipMalloc((void **)&t->Wb, t->nparam * 4 + 256));
+        HIP_TRY(hipMalloc((void **)&t->WTb, t->nparam * 4 + 256));
+    }
     return COCR_OK;
 }
 
@@ -294,17 +302,28 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     };
     // Y (rows, Nc) = X (rows, Kr) W(Nc, Kr)^T + b
     auto lin_fwd = [&](const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *Y) -> int {
+        if (t->matmul_bf16 && t->Wb && Nc % 8 == 0 && Kr % 8 == 0) {
+            // 'medium': the weight's bf16 copy AND its bf16 transpose (the input-gradient product's operand) in one pass, kept for the backward
+            const size_t wo = t->idx.at(w).off * 4;
+            bf16_t *Wb = reinterpret_cast<bf16_t *>(t->Wb + wo), *WT = reinterpret_cast<bf16_t *>(t->WTb + wo);
+            hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(Nc, 32)), dim3(256), 0, s, Pp(w), WT, Wb, nullptr, Nc, Kr, Nc);
+            const bf16_t *Ab = to_bf16(X, oBfA, (size_t)rows * Kr);
+            EpiStoreF32 e{Y, Nc, b.empty() ? nullptr : Pp(b), Nc};
+            GEMM_TRY(launch_gemm<bf16_t>(s, Ab, Kr, Wb, Kr, rows, Nc, Kr, e));
+            return COCR_OK;
+        }
         return gemm(X, Kr, Pp(w), Kr, rows, Nc, Kr, Y, Nc, b.empty() ? nullptr : Pp(b));
     };
     // dW += dY^T X, db += colsum(dY), dX = dY W   (dX null: not wanted).  dY (rows, Nc), X (rows, Kr)
     auto lin_bwd = [&](const float *dY, const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *dX) -> int {
         const int splits = wg_splits(Nc, Kr), rp = round_up(rows, (t->matmul_bf16 ? 64 : 32) * splits);
         int r;
-        if (t->matmul_bf16 && Nc % 8 == 0 && Kr % 8 == 0) {
+        if (t->matmul_bf16 && t->Wb && Nc % 8 == 0 && Kr % 8 == 0) {
             // 'medium': every operand is read ONCE in fp32 and leaves as the bf16 copies the two products take (k_transpose_bf16); the bias
             // gradient's partial sums ride on the pass over dY.  8 launches instead of 12, a third of the bytes.
             bf16_t *dYT = reinterpret_cast<bf16_t *>(t->ws + oBfA), *XT = reinterpret_cast<bf16_t *>(t->ws + oBfW);
-            bf16_t *dYR = reinterpret_cast<bf16_t *>(WS(oTA)), *WT = reinterpret_cast<bf16_t *>(WS(oTW));
+            bf16_t *dYR = reinterpret_cast<bf16_t *>(WS(oTA));
+            const bf16_t *WT = reinterpret_cast<const bf16_t *>(t->WTb + t->idx.at(w).off * 4);          // written by lin_fwd of this step
             const bool fuse_bias = !b.empty() && colsum_chunk_rows(rows) == 32;
             hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Nc, 32), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYT, dX ? dYR : nullptr, fuse_bias ? WS(oPart) : nullptr, rows, Nc, rp);
             hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(rp, 32)), dim3(256), 0, s, X, XT, nullptr, nullptr, rows, Kr, rp);
@@ -321,7 +340,6 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
                 hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 64)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
             }
             if (dX) {
-                hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(Nc, 32)), dim3(256), 0, s, Pp(w), WT, nullptr, nullptr, Nc, Kr, Nc);      // W^T (Kr, Nc)
                 EpiStoreF32 e{dX, Kr, nullptr, Kr};
                 GEMM_TRY(launch_gemm<bf16_t>(s, dYR, Nc, WT, Nc, rows, Kr, Nc, e));
             }
@@ -356,6 +374,12 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     // dx (+)= LayerNorm backward of dy; d gamma, d beta
     auto ln_bwd = [&](const float *dy, const float *x, const float *mu, const float *rs, const std::string &g, const std::string &b, float *dx, int accumulate) {
         hipLaunchKernelGGL(k_ln_bwd, dim3(ceil_div(M, 4)), dim3(256), 0, s, dy, x, mu, rs, Pp(g), dx, WS(oDwide2), M, D, accumulate);
+        if (D % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)Gp(g) & 15) == 0 && ((uintptr_t)Gp(b) & 15) == 0) {      // d gamma and d beta in one pair of launches
+            const int rows = colsum_chunk_rows(M), chunks = ceil_div(M, rows);
+            hipLaunchKernelGGL(k_colsum_partial4_2, dim3(ceil_div(2 * D, 256), chunks), dim3(256), 0, s, WS(oDwide2), dy, WS(oPart), M, D, rows);
+            hipLaunchKernelGGL(k_colsum_final_2, dim3(ceil_div(2 * D, 64)), dim3(256), 0, s, WS(oPart), Gp(g), Gp(b), chunks, D);
+            return;
+        }
         colsum(WS(oDwide2), nullptr, M, D, Gp(g), 0);
         colsum(dy, nullptr, M, D, Gp(b), 0);
     };

@@ -117,6 +117,35 @@ __global__ __launch_bounds__(256) static void k_colsum_partial4(const float *__r
     __syncthreads();
     if (rg == 0 && n < N) *reinterpret_cast<f32x4 *>(part + (size_t)chunk * N + n) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
 }
+// Two matrices at once (a LayerNorm's d gamma and d beta operands; N % 4 == 0): part[chunk][2 N] = column sums of a1 | of a2 over the
+// chunk's rows, the same arrangement as k_colsum_partial4; k_colsum_final_2 adds the chunks (16 chunk groups in order) into out1 / out2.
+__global__ __launch_bounds__(256) static void k_colsum_partial4_2(const float *__restrict__ a1, const float *__restrict__ a2, float *__restrict__ part, int M, int N, int rows) {
+    __shared__ f32x4 red4[4][64];
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6, n2 = blockIdx.x * 256 + 4 * cq, chunk = blockIdx.y;      // n2: column of the (M, 2 N) pair
+    const int r0 = chunk * rows, r1 = min(M, r0 + rows);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n2 < 2 * N) {
+        const float *a = n2 < N ? a1 + n2 : a2 + (n2 - N);
+        for (int r = r0 + rg; r < r1; r += 4) s += *reinterpret_cast<const f32x4 *>(a + (size_t)r * N);
+    }
+    red4[rg][cq] = s;
+    __syncthreads();
+    if (rg == 0 && n2 < 2 * N) *reinterpret_cast<f32x4 *>(part + (size_t)chunk * 2 * N + n2) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
+}
+__global__ __launch_bounds__(256) static void k_colsum_final_2(const float *__restrict__ part, float *__restrict__ out1, float *__restrict__ out2, int chunks, int N) {
+    __shared__ f32x4 red4[16][16];
+    const int cq = threadIdx.x & 15, kg = threadIdx.x >> 4, n2 = blockIdx.x * 64 + 4 * cq;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n2 < 2 * N) for (int k = kg; k < chunks; k += 16) s += *reinterpret_cast<const f32x4 *>(part + (size_t)k * 2 * N + n2);
+    red4[kg][cq] = s;
+    __syncthreads();
+    if (kg == 0 && n2 < 2 * N) {
+        f32x4 tot = red4[0][cq];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tot += red4[k][cq];
+        *reinterpret_cast<f32x4 *>(n2 < N ? out1 + n2 : out2 + (n2 - N)) = tot;
+    }
+}
 // out[n] (+)= sum over `chunks` of part[k][n]: the same 64 x 4 arrangement over the chunks
 __global__ __launch_bounds__(256) static void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int chunks, int N, int accumulate) {
     __shared__ float red[4][64];
