@@ -38,6 +38,21 @@ __device__ __forceinline__ float max3_f(float a, float b, float c) {
     return r;
 }
 
+// EVERY inline-assembly consumer of matrix-instruction results goes through one of these fences: the compiler's hazard
+// recogniser does not see that such a statement reads registers a v_mfma has just written, and the hardware does not interlock a vector
+// read on a matrix result.  The accumulators are tied to the statement ("+v": every product is issued before it, every consumer after it)
+// and it holds the wait states of the longest pass of a 16x16x32 instruction (20).  Without it the resident kernel's results varied in the
+// last bit from run to run (a stale score moves only the running reference); tests/test_hip_determinism.py is the guard.
+#define COCR_MFMA_WAIT "s_nop 7\n\ts_nop 7\n\ts_nop 3"
+__device__ __forceinline__ void mfma_results_fence(f32x4 (&a)[4]) { asm volatile(COCR_MFMA_WAIT : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
+__device__ __forceinline__ void mfma_results_fence(f32x4 (&a)[4], f32x4 (&b)[4]) {
+    asm volatile(COCR_MFMA_WAIT : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void mfma_results_fence(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4]) {
+    asm volatile(COCR_MFMA_WAIT : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]),
+                 "+v"(c[3]));
+}
+
 #ifndef COCR_ATT_EXP
 #define COCR_ATT_EXP 0          // dev: timing experiments (wrong results): 1 no shift through LDS, 2 no positional products, 4 no exponentials,
                                // 8 no P.V products, 16 tiles staged once, 32 no content products, 64 no barriers
@@ -301,10 +316,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const T *__restri
                         for (int c = 0; c < KC; ++c) sc[tt] = mma16(load_frag(reinterpret_cast<const T *>(kr + frag_off(c))), qu[c], sc[tt]); }
                 }
             }
-            // sc = score - m_run (log2 units).  The maxima are inline assembly: the compiler's hazard recogniser does not know that they read what
-            // the matrix instructions above have just written (no hardware interlock either): the scores are tied to this statement, which
-            // holds the wait states of the longest pass (see the LDS-resident kernel below, where the missing wait showed as run-to-run noise)
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
+            // sc = score - m_run (log2 units).  The maxima are inline assembly (max3_f): fence first
+            mfma_results_fence(sc);
             float tmax = max3_f(sc[0][0], sc[0][1], sc[0][2]);
             tmax = max3_f(tmax, sc[0][3], sc[1][0]);
             tmax = max3_f(tmax, sc[1][1], sc[1][2]);
@@ -622,15 +635,10 @@ __device__ __forceinline__ void attn_full_tiles(const unsigned char *ks, const u
         }
         // ---- one softmax step per 64 keys and query tile (sc = score - m_run, log2 units), as in the tiled kernel
         bf16x8 pb[NT][2];
-        // The maxima below are inline assembly (max3_f): the compiler's hazard recogniser does not see that they read registers the matrix
-        // instructions above have just written, and the hardware does not interlock a vector read on a matrix result.  The scores are tied
-        // to this statement (so every product is issued before it, every maximum after it) and it holds the wait states of the longest pass.
-        // (Without it the kernel's results varied in the last bit from run to run: a stale score moves only the running reference.)
-#define AF_TIE(t) "+v"(sc[t][0]), "+v"(sc[t][1]), "+v"(sc[t][2]), "+v"(sc[t][3])
-        if constexpr (NT == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : AF_TIE(0));
-        else if constexpr (NT == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : AF_TIE(0), AF_TIE(1));
-        else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : AF_TIE(0), AF_TIE(1), AF_TIE(2));
-#undef AF_TIE
+        // The maxima below are inline assembly (max3_f): one fence for all query tiles' scores first
+        if constexpr (NT == 1) mfma_results_fence(sc[0]);
+        else if constexpr (NT == 2) mfma_results_fence(sc[0], sc[1]);
+        else mfma_results_fence(sc[0], sc[1], sc[2]);
         // (the steps below run over all query tiles before the next step starts, and the two uniform branches -- keys beyond the line, reference
         // moved -- are taken once for all tiles: a branch per tile would cut the tiles' chains into basic blocks that cannot interleave)
         float tmax[NT];
