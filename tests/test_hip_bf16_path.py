@@ -358,15 +358,16 @@ def test_skipped_zero_k_steps_of_the_padded_default_model_change_no_bit(layers, 
         np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize('n,w,widths', [(3, 232, [232, 137, 200]), (2, 1200, [1200, 1111]), (5, 61, None), (1, 2400, None)])
-def test_fused_frontend_of_the_default_model_equals_the_separate_kernels(n, w, widths, monkeypatch):
+@pytest.mark.parametrize('n,w,widths,height', [(3, 232, [232, 137, 200], 96), (2, 1200, [1200, 1111], 96), (5, 61, None, 96), (1, 2400, None, 96),
+                                              (3, 300, [300, 77, 201], 48), (2, 200, None, 128)])
+def test_fused_frontend_of_the_default_model_equals_the_separate_kernels(n, w, widths, height, monkeypatch):
     """32 conv channels (the reference's default model, default_specs.py:48-61): conv.0 + ReLU + depthwise conv.2 + pointwise conv.3 + ReLU
     run as ONE launch (conv.hip.h: frontend_conv12pw32_kernel; Z2 stays in LDS, the pointwise conv is one matrix instruction per 16
     positions x 16 channels).  A/B against the separate kernels (COCR_NO_FRONT32=1: VALU kernel -> Z2 in memory -> GEMM): the same
     rounding points (Z2 and Z3 are bf16 either way); the bias enters the accumulation at another place, which flips the bf16 rounding of
     about one Z3 element per line -- lines without a flip come out bit-identical, the others within the band every A/B of this file has
     (0.1 measured on logits of +-12; fused vs unfused 256-channel frontend: 0.25); u8 lines too; frame counts that are no multiple of 16."""
-    hp = synth.hparams('cfg1', num_encoder_layers=2)
+    hp = synth.hparams('cfg1', num_encoder_layers=2, height=height)          # (line heights 48 / 128: 12 / 32 feature rows per frame)
     state = synth.make_state_dict(hp, seed=9, decoder_gain=8.0)
     image, lens = synth.make_lines(n, hp.height, w, seed=13, widths=widths)
     for as_u8 in (False, True):
