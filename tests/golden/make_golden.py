@@ -294,6 +294,28 @@ def cfg2_cases(meta):
              line_seed=1237, reuse=reuse, style='text')
 
 
+# Round 4: hyper-parameter VARIANTS of the measured model, each through the reference itself -- other instantiations of the same kernels
+# (depthwise kernel sizes, head sizes, the eighth-rate frontend, the full-step residual, an odd class count, the wide model with a short
+# depthwise kernel, the reference's default model at the metric's line width).  Small batches: the fixtures hold full logits.
+VARIANTS = {
+    #  name: (base config, overrides, seed, lines, width, widths)
+    'v_k15':    ('cfg2', dict(num_encoder_layers=2, conv_kernel_size=15), 3101, 3, 400, [400, 333, 250]),
+    'v_k7':     ('cfg2', dict(num_encoder_layers=2, conv_kernel_size=7), 3102, 2, 264, [264, 199]),
+    'v_h8':     ('cfg2', dict(num_encoder_layers=2, num_attention_heads=8), 3103, 3, 400, [400, 287, 350]),
+    'v_nohalf': ('cfg2', dict(num_encoder_layers=2, half_step_residual=False, num_classes=97), 3104, 2, 328, [328, 240]),
+    'v_f8':     ('cfg2', dict(num_encoder_layers=2, subsampling_factor=8), 3105, 2, 480, [480, 391]),
+    'v_ff2':    ('cfg2', dict(num_encoder_layers=2, feed_forward_expansion_factor=2), 3106, 2, 296, [296, 180]),
+    'v_d512k7': ('cfg4', dict(num_encoder_layers=1, conv_kernel_size=7), 3107, 2, 360, [360, 299]),
+    'v_cfg1w':  ('cfg1', dict(), 3108, 2, 1200, [1200, 1040]),
+}
+
+
+def variant_cases(meta):
+    for name, (base, over, seed, n, W, widths) in VARIANTS.items():
+        hp = synth.hparams(base, **over)
+        run_case(meta, name, hp, seed, n, W, widths=widths, style='text')
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -304,10 +326,10 @@ def main():
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
-    if len(sys.argv) > 1 and sys.argv[1] in ('tiny2', 'long', 'text1', 'cfg2'):      # only that fixture, merged into the existing meta.json
+    if len(sys.argv) > 1 and sys.argv[1] in ('tiny2', 'long', 'text1', 'cfg2', 'variants'):      # only that fixture, merged into the existing meta.json
         with open(os.path.join(HERE, 'meta.json')) as fp:
             meta = json.load(fp)
-        {'tiny2': tiny2_case, 'long': long_case, 'text1': text_case_cfg1, 'cfg2': cfg2_cases}[sys.argv[1]](meta)
+        {'tiny2': tiny2_case, 'long': long_case, 'text1': text_case_cfg1, 'cfg2': cfg2_cases, 'variants': variant_cases}[sys.argv[1]](meta)
         with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
             json.dump(meta, fp, indent=1)
         return
@@ -331,6 +353,7 @@ def main():
     hp4 = synth.hparams('cfg4')
     run_case(meta, 'cfg4', hp4, 1238, 3, 1400, widths=[1400, 1256, 1208], head=1)
     text_cases(meta)
+    variant_cases(meta)
     with open(os.path.join(HERE, 'meta.json'), 'w') as fp:
         json.dump(meta, fp, indent=1)
     for f in sorted(os.listdir(HERE)):

@@ -31,6 +31,15 @@ BF16_CASES = {
     'cfg2':        (0.35, 0.272, 0.50, 390),      # 260 of 9600
     'cfg2_ragged': (0.38, 0.292, 0.50, 63),       # 42 of 1800
     'cfg4':        (0.38, 0.286, 0.20, 75),       # 49 of 1050
+    # hyper-parameter variants (round 4), measured like the others
+    'v_k15': (0.31, 0.241, 0.51, 11),      # 7 of 300
+    'v_k7': (0.33, 0.257, 0.51, 7),      # 4 of 132
+    'v_h8': (0.3, 0.231, 0.45, 6),      # 3 of 300
+    'v_nohalf': (0.33, 0.257, 0.5, 5),      # 2 of 164
+    'v_f8': (0.3, 0.230, 0.47, 3),      # 0 of 120
+    'v_ff2': (0.33, 0.253, 0.46, 11),      # 7 of 148
+    'v_d512k7': (0.3, 0.206, 0.48, 7),      # 4 of 180
+    'v_cfg1w': (0.43, 0.327, 0.36, 32),      # 21 of 600
 }
 
 
@@ -103,6 +112,25 @@ def _check_case(case, name, dtype, n=None):
 def test_fp32_logits_within_1e3(case, name):
     dev, mism, *_ = _check_case(case, name, 'fp32')
     assert dev <= FP32_TOL and mism == 0
+
+
+VARIANT_NAMES = ['v_k15', 'v_k7', 'v_h8', 'v_nohalf', 'v_f8', 'v_ff2', 'v_d512k7', 'v_cfg1w']
+
+
+@pytest.mark.parametrize('name', VARIANT_NAMES)
+def test_hyper_parameter_variants_against_the_reference(case, name):
+    """Round 4: other instantiations of the same kernels against vectors the reference itself produced (make_golden.py VARIANTS): depthwise
+    kernels 15 / 7 (the chain kernels' prologue only exists for 31: the stand-alone depthwise kernel runs in front of them), 8 heads of 32
+    (the 32-wide attention instantiation), the full-step feed-forward residual with 97 classes, subsampling factor 8 (a second depthwise /
+    pointwise stage behind the fused frontend), feed-forward expansion 2, the 512-wide model with kernel 7, the reference's default model at
+    1200-pixel lines.  fp32 within 1e-3 with every label outside 2e-3 equal; bf16 within the fixture's bound with every label outside
+    max(0.7, 2 x bound) equal."""
+    dev, mism, *_ = _check_case(case, name, 'fp32')
+    assert dev <= FP32_TOL and mism == 0
+    dev, mism, *_ = _check_case(case, name, 'bf16')
+    bound, _measured, min_share, max_all = BF16_CASES[name]
+    assert mism == 0 and dev <= bound, (dev, mism)
+    assert _check_case.last['checked_share'] >= min_share and _check_case.last['mism_all'] <= max_all, _check_case.last
 
 
 def test_line_longer_than_the_positional_table(case, golden_meta):

@@ -20,6 +20,21 @@ def test_oracle_matches_reference_logits(case, name):
     np.testing.assert_array_equal(logits.argmax(-1).numpy()[g['margins'] > 1e-3], g['labels'][g['margins'] > 1e-3])
 
 
+VARIANT_NAMES = ['v_k15', 'v_k7', 'v_h8', 'v_nohalf', 'v_f8', 'v_ff2', 'v_d512k7', 'v_cfg1w']
+
+
+@pytest.mark.parametrize('name', VARIANT_NAMES)
+def test_oracle_matches_reference_on_hyper_parameter_variants(case, name):
+    """Round 4: the restatement against the reference itself on other hyper-parameters of the measured model (make_golden.py VARIANTS:
+    depthwise kernels 15 / 7, 8 heads of 32, the full-step residual with 97 classes, subsampling factor 8, feed-forward expansion 2, the
+    wide model with kernel 7, the reference's default model at 1200-pixel lines)."""
+    hp, state, image, lens, g = case(name)
+    logits, olens = Oracle(hp, state, torch.float32).forward(torch.from_numpy(image), torch.from_numpy(lens))
+    assert olens.tolist() == g['out_lens'].tolist()
+    assert np.abs(logits.numpy() - g['logits']).max() <= TOL
+    np.testing.assert_array_equal(logits.argmax(-1).numpy()[g['margins'] > 1e-3], g['labels'][g['margins'] > 1e-3])
+
+
 def test_oracle_stage_taps_match_reference(case):
     hp, state, image, lens, g = case('tiny')
     taps = {}
