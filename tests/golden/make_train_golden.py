@@ -21,13 +21,17 @@ from conformer_ocr.conformer.encoder import ConformerEncoder  # noqa: E402  (the
 
 from conformer_ocr_amd import synth  # noqa: E402
 
-TARGETS = {'tiny_train': dict(config='tiny', seed=4321, n=3, W=64, widths=[64, 37, 50], targets=[[3, 1, 4], [1, 5], [9, 2, 6, 5]])}
+TARGETS = {'tiny_train': dict(config='tiny', seed=4321, n=3, W=64, widths=[64, 37, 50], targets=[[3, 1, 4], [1, 5], [9, 2, 6, 5]]),
+           # round 4: the metric model's shapes (D = 256, 4 heads of 64, 256 conv channels, kernel 31), two blocks, short ragged lines.  4.8 M
+           # parameters: per tensor the fixture holds 64 SAMPLED gradient entries (seeded indices) and its sum / sum of magnitudes / L2 norm /
+           # largest magnitude instead of the whole gradient.
+           'cfg2x2_train': dict(config='cfg2', over=dict(num_encoder_layers=2), seed=5, n=2, W=120, widths=[120, 77], targets=[[5, 9, 9, 3], [17]], sampled=64)}
 
 
 def main():
     torch.manual_seed(0)
     for name, t in TARGETS.items():
-        hp = synth.hparams(t['config'])
+        hp = synth.hparams(t['config'], **t.get('over', {}))
         state = synth.make_state_dict(hp, seed=t['seed'], decoder_gain=1.0)
         image, lens = synth.make_lines(t['n'], hp.height, t['W'], seed=t['seed'], widths=t['widths'])
         enc = ConformerEncoder(in_channels=1, input_dim=hp.height, encoder_dim=hp.encoder_dim, num_layers=hp.num_encoder_layers,
@@ -53,10 +57,18 @@ def main():
         loss.backward()
         out = {'loss': np.float64(loss.item()), 'probits': probits.detach().numpy(), 'out_lens': el.numpy(), 'target': target.numpy(),
                'target_lens': tl.numpy()}
-        for k, p in enc.named_parameters():
-            out['grad:encoder.' + k] = p.grad.numpy()
-        for k, p in dec.named_parameters():
-            out['grad:decoder.' + k] = p.grad.numpy()
+        named = [('encoder.' + k, p) for k, p in enc.named_parameters()] + [('decoder.' + k, p) for k, p in dec.named_parameters()]
+        if t.get('sampled'):
+            out['probits'] = out['probits'].astype(np.float32)
+            rng = np.random.default_rng(t['seed'])
+            for k, p in named:
+                gflat = p.grad.numpy().reshape(-1)
+                idx = np.sort(rng.choice(gflat.size, size=min(t['sampled'], gflat.size), replace=False)).astype(np.int64)
+                out['gi:' + k], out['gs:' + k] = idx, gflat[idx]
+                out['gn:' + k] = np.array([gflat.sum(), np.abs(gflat).sum(), np.sqrt((gflat ** 2).sum()), np.abs(gflat).max()])
+        else:
+            for k, p in named:
+                out['grad:' + k] = p.grad.numpy()
         for k, b in enc.named_buffers():
             if 'running_' in k or 'num_batches' in k:
                 out['buf:encoder.' + k] = b.detach().numpy()

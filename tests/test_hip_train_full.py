@@ -65,6 +65,35 @@ def test_every_gradient_against_autograd_of_the_oracle(name):
         assert np.abs(eng.train_value(p + 'running_var') - rv).max() <= 1e-5
 
 
+def test_training_step_against_the_reference_at_the_metric_models_shapes():
+    """tests/golden/cfg2x2_train.npz (round 4): the HIP training step against the REFERENCE's own float64 step at the metric model's shapes
+    (two blocks), without the oracle in between: loss, probits, and for every parameter the 64 sampled gradient entries and the gradient's
+    L2 norm / largest magnitude the fixture holds."""
+    import os
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'cfg2x2_train.npz'))
+    c = CASES['cfg2x2']
+    hp = c['hp']()
+    state = synth.make_state_dict(hp, seed=c['seed'], decoder_gain=c['gain'])
+    image, lens = synth.make_lines(c['n'], hp.height, c['W'], seed=c['seed'], widths=c['widths'])
+    eng = _engine(hp, state)
+    tg = [x for s in c['targets'] for x in s]
+    assert tg == g['target'].tolist()
+    loss = eng.train_step(torch.from_numpy(image[:, 0]).cuda(), lens, tg, [len(s) for s in c['targets']])
+    assert abs(loss - float(g['loss'])) <= 2e-4 * abs(float(g['loss'])), (loss, float(g['loss']))
+    bad, n = {}, 0
+    for k, (shape, kind) in model_state_spec(hp).items():
+        if kind != 'param':
+            continue
+        n += 1
+        got, ref, nrm = eng.train_grad(k).reshape(-1), g['gs:' + k], g['gn:' + k]
+        err = float(np.abs(got[g['gi:' + k]] - ref).max())
+        l2 = float(np.sqrt((got.astype(np.float64) ** 2).sum()))
+        if not (err <= 2e-3 * nrm[3] + 1e-5 and abs(l2 - nrm[2]) <= 2e-3 * nrm[2] + 1e-5 and abs(float(np.abs(got).max()) - nrm[3]) <= 2e-3 * nrm[3] + 1e-5):
+            bad[k] = (err, l2, nrm.tolist())
+    assert n == sum(1 for f in g.files if f.startswith('gi:')) and not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1][0])[:8])
+
+
 def test_adamw_steps_follow_torch_and_lower_the_loss():
     """Three optimizer steps on a fixed batch: after every step the parameters equal torch.optim.AdamW (fp32) fed with the SAME gradients
     (read back from the device: the gradients' own parity is the test above; Adam divides a gradient by its own magnitude, so feeding it

@@ -182,3 +182,26 @@ def test_oracle_train_mode_matches_the_reference_training_step():
         rm = 0.9 * state[p + 'running_mean'].astype(np.float64) + 0.1 * mu.numpy()
         rv = 0.9 * state[p + 'running_var'].astype(np.float64) + 0.1 * var.numpy() * M / (M - 1)
         assert np.abs(rm - g['buf:' + p + 'running_mean']).max() <= 1e-9 and np.abs(rv - g['buf:' + p + 'running_var']).max() <= 1e-9
+
+
+def test_oracle_train_mode_matches_the_reference_at_the_metric_models_shapes():
+    """tests/golden/cfg2x2_train.npz (round 4): the reference's training step in float64 at D = 256, 4 heads of 64, 256 conv channels, kernel
+    31, two blocks -- loss, probits, and per parameter 64 sampled gradient entries + sum / sum of magnitudes / L2 norm / largest magnitude."""
+    import os
+    from conformer_ocr_amd import synth
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'cfg2x2_train.npz'))
+    hp = synth.hparams('cfg2', num_encoder_layers=2)
+    state = synth.make_state_dict(hp, seed=5, decoder_gain=1.0)
+    image, lens = synth.make_lines(2, hp.height, 120, seed=5, widths=[120, 77])
+    loss, probits, grads, bn = oracle_train_grads(hp, state, image, lens, [[5, 9, 9, 3], [17]])
+    assert abs(loss - float(g['loss'])) <= 1e-9 * abs(float(g['loss']))
+    assert np.abs(probits - g['probits']).max() <= 1e-5
+    names = [k[3:] for k in g.files if k.startswith('gi:')]
+    assert sorted(names) == sorted(grads)
+    for k in names:
+        flat, n = grads[k].reshape(-1), g['gn:' + k]
+        assert np.abs(flat[g['gi:' + k]] - g['gs:' + k]).max() <= 1e-9 * max(1.0, n[3]), k
+        got = np.array([flat.sum(), np.abs(flat).sum(), np.sqrt((flat ** 2).sum()), np.abs(flat).max()])
+        assert np.abs(got - n).max() <= 1e-8 * max(1.0, n[1]), k
+
