@@ -955,10 +955,10 @@ static int forward_impl(cocr_model *m, const TIn *lines, int N, int H, int W, fl
     if constexpr (sizeof(T) == 2) {
         // 32 conv channels (the reference's default model): conv.0 + ReLU + depthwise conv.2 + pointwise conv.3 + ReLU in one launch
         // (conv.hip.h: frontend_conv12pw32_kernel); with debug taps the separate kernels run (Z2 exists there; same arithmetic)
-        if (C == 32 && F2 <= 32 && !m->debug && !m->no_front32) {
+        const size_t lds32 = (size_t)(4 * 16 + 3) * ((H + 11) & ~3) * 4 + (size_t)16 * F2 * 80;      // line tile + Z2 rows of 16 frames
+        if (C == 32 && F2 <= 32 && lds32 <= 160 * 1024 && !m->debug && !m->no_front32) {
             ProfScope ps(m, s, FAM_CONV12);
-            const int HS = (H + 11) & ~3;
-            const size_t lds = (size_t)(4 * 16 + 3) * HS * 4 + (size_t)16 * F2 * 80;
+            const size_t lds = lds32;
             auto kern = frontend_conv12pw32_kernel<TIn>;
             GEMM_TRY(raise_lds_limit((const void *)kern, lds));
             hipLaunchKernelGGL(kern, dim3(ceil_div(T2, 16), N), dim3(256), lds, s, lines, H, W, T1, F1, T2, F2, F32(P.w0), F32(P.b0),
