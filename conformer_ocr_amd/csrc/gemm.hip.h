@@ -581,6 +581,94 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs<T> p, Epi epi) 
     }
 }
 
+// ---- both operands K-MAJOR (round 4; the weight-gradient product of a training step: dW = dY^T X with dY (rows, N_out) and X (rows, K_in)
+// as the forward left them) ---------------------------------------------------------------------------------------------------------------
+//     out (M, N) = sum_k A[k][m] B[k][n]        A: (K, M) row-major, lda;  B: (K, N) row-major, ldb;  bf16, fp32 accumulation
+// No transposed copies: a k-tile of 32 rows x 128 columns of each operand goes to LDS as it lies in memory (LDS-DMA, 256-byte rows, the
+// 16-byte chunk c of row r stored at chunk c ^ 2 (r & 7)), and the MFMA fragments -- 8 consecutive k of one column per lane -- are read
+// with ds_read_b64_tr_b16 (two per fragment: rows 4 g + q and 16 + 4 g + q; both operands see the same permutation of k inside a chunk,
+// which a product does not notice).  The swizzle puts the 8 rows a 32-lane half touches (32 bytes each) on all 64 banks.
+// Requirements: M % 8 == 0, N % 8 == 0, K % 32 == 0 (the callers pad the rows with zeros), 16-byte aligned bases and leading dimensions.
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<bf16_t> p, EpiStoreF32 epi) {
+    typedef bf16_t T;
+    constexpr int BK = 32, MI = BM / 32, NI = BN / 32;
+    constexpr int AROW = BM * 2, BROW = BN * 2;              // bytes per LDS row
+    constexpr int STAGE = BK * (AROW + BROW);
+    constexpr int PA = BK * AROW / 1024 / 4, PB = BK * BROW / 1024 / 4;      // DMA wave-instructions per wave and k-tile
+    static_assert(BM == 128 && BN == 128, "one 1 KiB wave-instruction = 4 rows of 256 bytes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = p.M, N = p.N, K = p.K;                     // K: this launch's (split's) depth
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int gx = (N + BN - 1) / BN;
+    const int ltile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (ltile / gx) * BM, n0 = (ltile % gx) * BN;
+    const int nk = K / BK;
+    const size_t kz = (size_t)blockIdx.y * p.k_zstride;      // split-K: this split's first k row
+    const unsigned char *Ab = reinterpret_cast<const unsigned char *>(p.A + kz * p.lda), *Bb = reinterpret_cast<const unsigned char *>(p.W + kz * p.ldw);
+    // DMA pieces of this lane: LDS slot (row r = 4 instr + (lane >> 4), chunk s = lane & 15) <- global chunk s ^ 2 (r & 7) of that row
+    // (clamped to the operand's last chunk: columns beyond M / N feed only outputs nobody stores)
+    unsigned offA[PA], offB[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int r = 4 * (wave + 4 * i) + (lane >> 4), c = (lane & 15) ^ (2 * (r & 7));
+        offA[i] = (unsigned)r * (unsigned)(p.lda * 2) + (unsigned)min(m0 + 8 * c, M - 8) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int r = 4 * (wave + 4 * i) + (lane >> 4), c = (lane & 15) ^ (2 * (r & 7));
+        offB[i] = (unsigned)r * (unsigned)(p.ldw * 2) + (unsigned)min(n0 + 8 * c, N - 8) * 2u;
+    }
+    auto issue = [&](int kt) {
+        unsigned char *st = smem + (kt % NST) * STAGE;
+        const unsigned char *ab = Ab + (size_t)kt * BK * p.lda * 2, *bb = Bb + (size_t)kt * BK * p.ldw * 2;      // uniform
+#pragma unroll
+        for (int i = 0; i < PA; ++i) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ab + offA[i]), (lds_ptr_t)(st + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bb + offB[i]), (lds_ptr_t)(st + BK * AROW + (wave + 4 * i) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) issue(t);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // transposed fragment of the 16 columns from `col0` of a [BK][cols] tile: lane 16 g + 4 q + pp reads 8 bytes of row 4 g + q (and 16 rows
+    // on), columns col0 + 4 pp .. + 3, and receives column (lane & 15) of the four rows
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    auto tr_frag = [&](const unsigned char *tile, int rowb, int col0) {
+        typedef __attribute__((address_space(3))) bf16x4 *lp;
+        const int r = 4 * g + q, ch = (col0 >> 3) + (pp >> 1);
+        const unsigned char *p0 = tile + r * rowb + ((ch ^ (2 * (r & 7))) << 4) + 8 * (pp & 1);
+        const unsigned char *p1 = tile + (r + 16) * rowb + ((ch ^ (2 * ((r + 16) & 7))) << 4) + 8 * (pp & 1);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)p0), hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)p1);
+        return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        const int after = min(nk, kt + NST - 1) - (kt + 1);
+        if (after >= 2) wait_vmcnt<2 * (PA + PB)>(); else if (after == 1) wait_vmcnt<PA + PB>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nk) issue(kt + NST - 1);
+        const unsigned char *sa = smem + (kt % NST) * STAGE, *sb = sa + BK * AROW;
+        bf16x8 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = tr_frag(sa, AROW, wm * (BM / 2) + 16 * i);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = tr_frag(sb, BROW, wn * (BN / 2) + 16 * j);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = mma16(b[j], a[i], acc[i][j]);   // swapped: rows = n, columns = m
+    }
+    __syncthreads();
+    EpiStoreF32 ez = epi.with_z(p.k_zstride ? blockIdx.y : 0);
+    gemm_epilogue<BM, BN, MI, NI, EpiStoreF32>(acc, smem, m0, n0, M, N, ez);
+}
+
 // ---- register-staged kernel (any k tail) ---------------------------------------------------------------------
 template <typename T, int BM, int BN, typename Epi>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs<T> p, Epi epi) {
@@ -850,3 +938,20 @@ static inline hipError_t launch_gemm_splitk(hipStream_t s, const T *A, int lda, 
     hipLaunchKernelGGL(kern, dim3(ceil_div(N, BN) * ceil_div(M, BM), splits), dim3(256), lds, s, a, e);
     return hipGetLastError();
 }
+
+// out (M, N) (or `splits` partial sums at partial + z M N, to be added by the caller) = A^T B for K-major A (K, M) and B (K, N)
+static inline hipError_t launch_gemm_tn(hipStream_t s, const bf16_t *A, int lda, const bf16_t *B, int ldb, int M, int N, int K, int splits, float *out) {
+    constexpr int BM = 128, BN = 128, NST = 4;
+    if (splits < 1 || K % (splits * 32) || M % 8 || N % 8 || lda % 8 || ldb % 8) return hipErrorInvalidValue;
+    if ((size_t)K * lda * 2 >= ((size_t)1 << 32) - 256 || (size_t)K * ldb * 2 >= ((size_t)1 << 32) - 256) return hipErrorInvalidValue;      // (32-bit row offsets inside a split)
+    GemmArgs<bf16_t> a{A, lda, B, ldb, M, N, K / splits, splits > 1 ? K / splits : 0};
+    EpiStoreF32 e{out, N, nullptr, N};
+    e.zstride = (size_t)M * N;
+    const size_t lds = std::max((size_t)NST * 32 * (BM + BN) * 2, epi_lds_bytes<EpiStoreF32, BM, BN>());
+    auto kern = gemm_tn_kernel<BM, BN, NST>;
+    hipError_t err = raise_lds_limit((const void *)kern, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(N, BN) * ceil_div(M, BM), splits), dim3(256), lds, s, a, e);
+    return hipGetLastError();
+}
+

@@ -24,6 +24,10 @@ struct TrainState {
     float *pe = nullptr;                      // sinusoid rows for relative positions T-1 ... -(T-1), (2T-1, D)
     int peT = 0;
     bool matmul_bf16 = false;                 // cocr_train_set_matmul: the Linear / pointwise-conv products on bf16-rounded operands (fp32 accumulate)
+    bool no_tn = false;                            // COCR_TRAIN_NO_TN=1 (read at cocr_train_set_matmul): weight gradients on transposed copies (A/B)
+    unsigned char *Xb = nullptr;                   // 'medium': the bf16 copy of every Linear's input (rows zero-padded to the weight-gradient product's depth), written by the
+    size_t Xb_bytes = 0, Xb_used = 0;              // forward, read by the backward as a K-major operand (gemm_tn_kernel): bump-allocated per step, offsets by weight name
+    std::map<std::string, size_t> Xb_off;
     unsigned char *Wb = nullptr, *WTb = nullptr;   // 'medium': bf16 copies of every Linear weight (N, K) and of its transpose (K, N), written by the forward, read by the
                                               // backward (byte offset of a tensor = its float offset x 4: 16-byte aligned like the fp32 tensors)
 };
@@ -31,7 +35,7 @@ struct TrainState {
 static void train_free(cocr_model *m) {
     TrainState *t = m->train;
     if (!t) return;
-    for (void *p : {(void *)t->P, (void *)t->G, (void *)t->Mo, (void *)t->Vo, (void *)t->ws, (void *)t->pe, (void *)t->Wb, (void *)t->WTb})
+    for (void *p : {(void *)t->P, (void *)t->G, (void *)t->Mo, (void *)t->Vo, (void *)t->ws, (void *)t->pe, (void *)t->Wb, (void *)t->WTb, (void *)t->Xb})
         if (p) (void)hipFree(p);
     delete t;
     m->train = nullptr;
@@ -44,6 +48,7 @@ extern "C" int cocr_train_set_matmul(cocr_model *m, int bf16_operands) {
     if (!m->train) return fail(COCR_ESTATE, "cocr_train_begin first");
     TrainState *t = m->train;
     t->matmul_bf16 = bf16_operands != 0;
+    { const char *e = getenv("COCR_TRAIN_NO_TN"); t->no_tn = e && e[0] == '1'; }
     if (t->matmul_bf16 && !t->Wb) {
         HIP_TRY(hipSetDevice(m->device));
         HIP_TRY(hipMalloc((void **)&t->Wb, t->nparam * 4 + 256));
@@ -238,6 +243,21 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     for (auto nk : {std::pair<int, int>{ff, D}, {D, ff}, {D, D}, {2 * D, D}, {C, C}, {D, C * F}, {ncls, D}})
         split_floats = std::max(split_floats, (size_t)wg_splits(nk.first, nk.second) * nk.first * nk.second);
     const size_t oSplit = rsv(split_floats), oLinePart = rsv((size_t)N * std::max((size_t)R * D, (size_t)ceil_div(T, COCR_DW_WC) * D * K));
+    if (t->matmul_bf16) {
+        // upper bound of the Linear inputs of one step (every row count padded by at most 64 x 32 rows)
+        const size_t pad = 2048;
+        size_t elems = (size_t)L * ((M + pad) * (size_t)(2 * (D + ff) + 6 * D) + (R + pad) * (size_t)D) + (size_t)snum * (big_rows + pad) * C + (M + pad) * ((size_t)C * F + D);
+        const size_t bytes = elems * 2 + (size_t)(8 * L + 16) * 256;
+        if (bytes > t->Xb_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (t->Xb) (void)hipFree(t->Xb);
+            t->Xb = nullptr; t->Xb_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&t->Xb, bytes));
+            t->Xb_bytes = bytes;
+        }
+        t->Xb_used = 0;
+        t->Xb_off.clear();
+    }
     if (need > t->ws_bytes) {
         HIP_TRY(hipDeviceSynchronize());
         if (t->ws) (void)hipFree(t->ws);
@@ -307,7 +327,14 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             const size_t wo = t->idx.at(w).off * 4;
             bf16_t *Wb = reinterpret_cast<bf16_t *>(t->Wb + wo), *WT = reinterpret_cast<bf16_t *>(t->WTb + wo);
             hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(Nc, 32)), dim3(256), 0, s, Pp(w), WT, Wb, nullptr, Nc, Kr, Nc);
-            const bf16_t *Ab = to_bf16(X, oBfA, (size_t)rows * Kr);
+            // the input's bf16 copy is kept for the backward (K-major operand of dW = dY^T X: rows zero-padded to that product's depth)
+            const int rp = round_up(rows, 64 * wg_splits(Nc, Kr));
+            const size_t xo = t->Xb_used, xbytes = ((size_t)rp * Kr * 2 + 255) / 256 * 256;
+            if (xo + xbytes > t->Xb_bytes) return fail(COCR_ESTATE, "training: bf16 activation arena too small (%zu + %zu > %zu)", xo, xbytes, t->Xb_bytes);
+            t->Xb_used += xbytes;
+            t->Xb_off[w] = xo;
+            bf16_t *Ab = reinterpret_cast<bf16_t *>(t->Xb + xo);
+            hipLaunchKernelGGL(k_rows_bf16, dim3(ceil_div(Kr, 256), ceil_div(rp, 32)), dim3(256), 0, s, X, Ab, nullptr, rows, Kr, rp);
             EpiStoreF32 e{Y, Nc, b.empty() ? nullptr : Pp(b), Nc};
             GEMM_TRY(launch_gemm<bf16_t>(s, Ab, Kr, Wb, Kr, rows, Nc, Kr, e));
             return COCR_OK;
@@ -319,26 +346,34 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         const int splits = wg_splits(Nc, Kr), rp = round_up(rows, (t->matmul_bf16 ? 64 : 32) * splits);
         int r;
         if (t->matmul_bf16 && t->Wb && Nc % 8 == 0 && Kr % 8 == 0) {
-            // 'medium': every operand is read ONCE in fp32 and leaves as the bf16 copies the two products take (k_transpose_bf16); the bias
-            // gradient's partial sums ride on the pass over dY.  8 launches instead of 12, a third of the bytes.
-            bf16_t *dYT = reinterpret_cast<bf16_t *>(t->ws + oBfA), *XT = reinterpret_cast<bf16_t *>(t->ws + oBfW);
+            // 'medium': dY is read ONCE in fp32 and leaves as the bf16 row-major copy both products take (k_rows_bf16: rows zero-padded to the
+            // weight-gradient product's depth, the bias gradient's partial sums on the way); X's copy is the forward's; the weight gradient
+            // dW = dY^T X reads both K-major (gemm_tn_kernel: no transposed copies), the input gradient takes the forward's W^T.
             bf16_t *dYR = reinterpret_cast<bf16_t *>(WS(oTA));
+            const bf16_t *XR = reinterpret_cast<const bf16_t *>(t->Xb + t->Xb_off.at(w));
             const bf16_t *WT = reinterpret_cast<const bf16_t *>(t->WTb + t->idx.at(w).off * 4);          // written by lin_fwd of this step
             const bool fuse_bias = !b.empty() && colsum_chunk_rows(rows) == 32;
-            hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Nc, 32), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYT, dX ? dYR : nullptr, fuse_bias ? WS(oPart) : nullptr, rows, Nc, rp);
-            hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(rp, 32)), dim3(256), 0, s, X, XT, nullptr, nullptr, rows, Kr, rp);
-            if (fuse_bias) {                       // (before the split-K product below re-uses no buffer of it: oPart is the sums' own)
+            if (t->no_tn) {
+                // COCR_TRAIN_NO_TN=1 (A/B of the test): the weight-gradient product on transposed bf16 copies, as before gemm_tn_kernel existed
+                bf16_t *dYT = reinterpret_cast<bf16_t *>(t->ws + oBfA), *XT = reinterpret_cast<bf16_t *>(t->ws + oBfW);
+                hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Nc, 32), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYT, dX ? dYR : nullptr, fuse_bias ? WS(oPart) : nullptr, rows, Nc, rp);
+                hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(rp, 32)), dim3(256), 0, s, X, XT, nullptr, nullptr, rows, Kr, rp);
+                if (splits == 1) {
+                    EpiStoreF32 e{Gp(w), Kr, nullptr, Kr};
+                    GEMM_TRY(launch_gemm<bf16_t>(s, dYT, rp, XT, rp, Nc, Kr, rp, e));
+                } else {
+                    GEMM_TRY(launch_gemm_splitk<bf16_t>(s, dYT, rp, XT, rp, Nc, Kr, rp, splits, WS(oSplit)));
+                }
+            } else {
+                hipLaunchKernelGGL(k_rows_bf16, dim3(ceil_div(Nc, 256), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYR, fuse_bias ? WS(oPart) : nullptr, rows, Nc, rp);
+                GEMM_TRY(launch_gemm_tn(s, dYR, Nc, XR, Kr, Nc, Kr, rp, splits, splits == 1 ? Gp(w) : WS(oSplit)));
+            }
+            if (splits > 1) hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 64)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
+            if (fuse_bias) {
                 const int chunks = ceil_div(rows, 32);
                 if (Nc % 4 == 0 && chunks > 32) hipLaunchKernelGGL(k_colsum_final4, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), Gp(b), chunks, Nc, 0);
                 else hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), Gp(b), chunks, Nc, 0);
             } else if (!b.empty()) colsum(dY, nullptr, rows, Nc, Gp(b), 0);
-            if (splits == 1) {
-                EpiStoreF32 e{Gp(w), Kr, nullptr, Kr};
-                GEMM_TRY(launch_gemm<bf16_t>(s, dYT, rp, XT, rp, Nc, Kr, rp, e));
-            } else {
-                GEMM_TRY(launch_gemm_splitk<bf16_t>(s, dYT, rp, XT, rp, Nc, Kr, rp, splits, WS(oSplit)));
-                hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 64)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
-            }
             if (dX) {
                 EpiStoreF32 e{dX, Kr, nullptr, Kr};
                 GEMM_TRY(launch_gemm<bf16_t>(s, dYR, Nc, WT, Nc, rows, Kr, Nc, e));

@@ -75,6 +75,26 @@ __global__ __launch_bounds__(256) static void k_transpose_bf16(const float *__re
         part[(size_t)blockIdx.y * C + c0 + tx] = sum;
     }
 }
+// 'medium' matmul precision: the bf16 row-major copy of an fp32 (R, C) matrix with its rows padded by zeros to Rp (the K-major operand of the
+// weight-gradient product gemm_tn_kernel, whose depth is a multiple of 32 x the split count), and -- part != null -- the column sums of every
+// 32-row tile in a fixed order (the bias gradient's partial sums).  C % 4 == 0.  A thread = four columns x every fourth row of a 32-row tile.
+__global__ __launch_bounds__(256) static void k_rows_bf16(const float *__restrict__ in, bf16_t *__restrict__ out, float *__restrict__ part, int R, int C, int Rp) {
+    __shared__ f32x4 red4[4][64];
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 256 + 4 * cq, r0 = blockIdx.y * 32;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < C) {
+        for (int r = r0 + rg; r < min(r0 + 32, Rp); r += 4) {
+            const f32x4 v = r < R ? *reinterpret_cast<const f32x4 *>(in + (size_t)r * C + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += v;
+            *reinterpret_cast<bf16x4 *>(out + (size_t)r * C + n) = (bf16x4){(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+    }
+    if (part) {
+        red4[rg][cq] = s;
+        __syncthreads();
+        if (rg == 0 && n < C && r0 < R) *reinterpret_cast<f32x4 *>(part + (size_t)blockIdx.y * C + n) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
+    }
+}
 // out (M, ldo) <- in (M, C), columns C..ldo-1 zero
 __global__ static void k_pad_cols(const float *__restrict__ in, float *__restrict__ out, int M, int C, int ldo) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * ldo; i += (size_t)gridDim.x * blockDim.x) {

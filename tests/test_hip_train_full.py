@@ -218,6 +218,39 @@ def test_medium_matmul_precision_stays_close_to_the_exact_step():
     assert b.train_step(x, lens, tg, tl) == lb and np.array_equal(g1, b.train_grad('decoder.weight'))
 
 
+def test_weight_gradients_from_k_major_operands_equal_those_from_transposed_copies(monkeypatch):
+    """'medium' precision, round 4: dW = dY^T X straight from the row-major bf16 copies of dY and X (gemm_tn_kernel: ds_read_b64_tr_b16
+    fragments, no transposed copies) against the same product on transposed copies (COCR_TRAIN_NO_TN=1: the form before).  The same bf16
+    operands, the same split of the rows over workgroups; only the order of the 32 products inside a k-chunk differs: every gradient within
+    1e-5 of its tensor's largest entry, the loss bit-equal (the forward is the same code)."""
+    c = CASES['cfg2x2']
+    hp = c['hp']()
+    state = synth.make_state_dict(hp, seed=c['seed'], decoder_gain=1.0)
+    image, lens = synth.make_lines(5, hp.height, 400, seed=19, widths=[400, 137, 333, 200, 64])
+    tg, tl = [5, 9, 9, 3, 17, 2, 2, 40, 7, 7, 1], [4, 1, 3, 2, 1]
+    x = torch.from_numpy(image[:, 0]).cuda()
+
+    def run():
+        e = HipRecognizer(hp, torch.device('cuda', 0), 'fp32')
+        e.load_state(state)
+        e.train_begin('medium')
+        return e, e.train_step(x, lens, tg, tl)
+    monkeypatch.setenv('COCR_TRAIN_NO_TN', '1')
+    a, la = run()
+    monkeypatch.delenv('COCR_TRAIN_NO_TN')
+    b, lb = run()
+    assert la == lb
+    names = [k for k, (shape, kind) in model_state_spec(hp).items() if kind == 'param']
+    scale = max(float(np.abs(a.train_grad(k)).max()) for k in names)        # (the key projection's bias has an exactly zero gradient: absolute floor)
+    bad = {}
+    for k in names:
+        ref, got = a.train_grad(k), b.train_grad(k)
+        err, top = float(np.abs(got - ref).max()), float(np.abs(ref).max())
+        if not err <= 1e-5 * top + 1e-6 * scale:
+            bad[k] = (err, top)
+    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1][0])[:8])
+
+
 def test_trainer_follows_the_reference_training_loop():
     """conformer_ocr_amd.train.Trainer = training_step + configure_optimizers + optimizer_step / lr_scheduler_step of the reference
     (model.py:147-152,238-321): warm-up exactly as the reference applies it, epoch-wise schedules equal to torch's schedulers, the loss
