@@ -24,6 +24,10 @@ struct TrainState {
     float *pe = nullptr;                      // sinusoid rows for relative positions T-1 ... -(T-1), (2T-1, D)
     int peT = 0;
     bool matmul_bf16 = false;                 // cocr_train_set_matmul: the Linear / pointwise-conv products on bf16-rounded operands (fp32 accumulate)
+    float *parts = nullptr;                        // partial column sums of the step's deferred finals (k_colsum_final_jobs), bump-allocated per step
+    size_t parts_floats = 0, parts_used = 0;
+    std::vector<ColsumJob> jobs;
+    ColsumJob *jobs_host = nullptr, *jobs_dev = nullptr;      // pinned staging + device copy of the job table (COCR_MAX_COLSUM_JOBS entries)
     bool no_tn = false;                            // COCR_TRAIN_NO_TN=1 (read at cocr_train_set_matmul): weight gradients on transposed copies (A/B)
     unsigned char *Xb = nullptr;                   // 'medium': the bf16 copy of every Linear's input (rows zero-padded to the weight-gradient product's depth), written by the
     size_t Xb_bytes = 0, Xb_used = 0;              // forward, read by the backward as a K-major operand (gemm_tn_kernel): bump-allocated per step, offsets by weight name
@@ -35,8 +39,10 @@ struct TrainState {
 static void train_free(cocr_model *m) {
     TrainState *t = m->train;
     if (!t) return;
-    for (void *p : {(void *)t->P, (void *)t->G, (void *)t->Mo, (void *)t->Vo, (void *)t->ws, (void *)t->pe, (void *)t->Wb, (void *)t->WTb, (void *)t->Xb})
+    for (void *p : {(void *)t->P, (void *)t->G, (void *)t->Mo, (void *)t->Vo, (void *)t->ws, (void *)t->pe, (void *)t->Wb, (void *)t->WTb, (void *)t->Xb, (void *)t->parts,
+                    (void *)t->jobs_dev})
         if (p) (void)hipFree(p);
+    if (t->jobs_host) (void)hipHostFree(t->jobs_host);
     delete t;
     m->train = nullptr;
 }
@@ -243,6 +249,22 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
     for (auto nk : {std::pair<int, int>{ff, D}, {D, ff}, {D, D}, {2 * D, D}, {C, C}, {D, C * F}, {ncls, D}})
         split_floats = std::max(split_floats, (size_t)wg_splits(nk.first, nk.second) * nk.first * nk.second);
     const size_t oSplit = rsv(split_floats), oLinePart = rsv((size_t)N * std::max((size_t)R * D, (size_t)ceil_div(T, COCR_DW_WC) * D * K));
+    {   // deferred column-sum finals: at most 12 jobs per block + the frontend's and the decoder's, each up to ceil(M / 32) x (widest matrix) partial sums
+        const size_t pf = (size_t)(12 * L + 16) * (size_t)ceil_div(M, 32) * (size_t)std::max(wide, 2 * D) + 4096;
+        if (pf > t->parts_floats) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (t->parts) (void)hipFree(t->parts);
+            t->parts = nullptr; t->parts_floats = 0;
+            HIP_TRY(hipMalloc((void **)&t->parts, pf * 4));
+            t->parts_floats = pf;
+        }
+        if (!t->jobs_host) {
+            HIP_TRY(hipHostMalloc((void **)&t->jobs_host, COCR_MAX_COLSUM_JOBS * sizeof(ColsumJob)));
+            HIP_TRY(hipMalloc((void **)&t->jobs_dev, COCR_MAX_COLSUM_JOBS * sizeof(ColsumJob)));
+        }
+        t->parts_used = 0;
+        t->jobs.clear();
+    }
     if (t->matmul_bf16) {
         // upper bound of the Linear inputs of one step (every row count padded by at most 64 x 32 rows)
         const size_t pad = 2048;
@@ -312,6 +334,28 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         hipLaunchKernelGGL(k_btranspose, dim3(ceil_div(Tk, 32), ceil_div(T, 32), Z), dim3(256), 0, s, in, out, T, T, (long long)Tk, (long long)Tk, Tk, 1, sTT, 0ll, sTT,
                            drop ? T : 0, p, (unsigned long long)seed, site);
     };
+    // Deferred finals: `part_alloc` hands out a region of this step's partial-sum arena (null: arena or job table full -> the caller does the
+    // final at once, as before), `defer_final` queues "out[n] = sum over chunks of part[chunk * stride + n]"; `flush_finals` (end of the
+    // backward pass) runs them all in one launch.
+    auto part_alloc = [&](size_t n) -> float * {
+        n = (n + 63) / 64 * 64;
+        if (t->parts_used + n > t->parts_floats || t->jobs.size() + 2 > COCR_MAX_COLSUM_JOBS) return nullptr;
+        float *p0 = t->parts + t->parts_used;
+        t->parts_used += n;
+        return p0;
+    };
+    auto defer_final = [&](const float *part, int stride, int chunks, int Nc, float *out) {
+        const int fb = t->jobs.empty() ? 0 : t->jobs.back().first_block + ceil_div(t->jobs.back().N, 64);
+        t->jobs.push_back(ColsumJob{part, out, stride, chunks, Nc, fb});
+    };
+    auto flush_finals = [&]() {
+        if (t->jobs.empty()) return;
+        const int total = t->jobs.back().first_block + ceil_div(t->jobs.back().N, 64);
+        memcpy(t->jobs_host, t->jobs.data(), t->jobs.size() * sizeof(ColsumJob));
+        (void)hipMemcpyAsync(t->jobs_dev, t->jobs_host, t->jobs.size() * sizeof(ColsumJob), hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_colsum_final_jobs, dim3(total), dim3(256), 0, s, t->jobs_dev, (int)t->jobs.size());
+        t->jobs.clear();
+    };
     auto colsum = [&](const float *a, const float *b, int Mr, int Nc, float *out, int accumulate) {
         const int rows = colsum_chunk_rows(Mr), chunks = ceil_div(Mr, rows);
         const bool vec = Nc % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0;
@@ -319,6 +363,14 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         else hipLaunchKernelGGL(k_colsum_partial, dim3(ceil_div(Nc, 64), chunks), dim3(256), 0, s, a, b, WS(oPart), Mr, Nc, rows);
         if (vec && chunks > 32) hipLaunchKernelGGL(k_colsum_final4, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
         else hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), out, chunks, Nc, accumulate);
+    };
+    // a gradient accumulator's column sums (bias gradients): the partial sums now, the final with the step's other finals
+    auto colsum_grad = [&](const float *a, int Mr, int Nc, float *out) {
+        const int rows = colsum_chunk_rows(Mr), chunks = ceil_div(Mr, rows);
+        float *gp = (Nc % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)out & 15) == 0) ? part_alloc((size_t)chunks * Nc) : nullptr;
+        if (!gp) { colsum(a, nullptr, Mr, Nc, out, 0); return; }
+        hipLaunchKernelGGL(k_colsum_partial4, dim3(ceil_div(Nc, 256), chunks), dim3(256), 0, s, a, (const float *)nullptr, gp, Mr, Nc, rows);
+        defer_final(gp, Nc, chunks, Nc, out);
     };
     // Y (rows, Nc) = X (rows, Kr) W(Nc, Kr)^T + b
     auto lin_fwd = [&](const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *Y) -> int {
@@ -352,11 +404,12 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             bf16_t *dYR = reinterpret_cast<bf16_t *>(WS(oTA));
             const bf16_t *XR = reinterpret_cast<const bf16_t *>(t->Xb + t->Xb_off.at(w));
             const bf16_t *WT = reinterpret_cast<const bf16_t *>(t->WTb + t->idx.at(w).off * 4);          // written by lin_fwd of this step
-            const bool fuse_bias = !b.empty() && colsum_chunk_rows(rows) == 32;
+            float *bpart = (!b.empty() && colsum_chunk_rows(rows) == 32 && ((uintptr_t)Gp(b) & 15) == 0) ? part_alloc((size_t)ceil_div(rows, 32) * Nc) : nullptr;
+            const bool fuse_bias = bpart != nullptr;
             if (t->no_tn) {
                 // COCR_TRAIN_NO_TN=1 (A/B of the test): the weight-gradient product on transposed bf16 copies, as before gemm_tn_kernel existed
                 bf16_t *dYT = reinterpret_cast<bf16_t *>(t->ws + oBfA), *XT = reinterpret_cast<bf16_t *>(t->ws + oBfW);
-                hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Nc, 32), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYT, dX ? dYR : nullptr, fuse_bias ? WS(oPart) : nullptr, rows, Nc, rp);
+                hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Nc, 32), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYT, dX ? dYR : nullptr, bpart, rows, Nc, rp);
                 hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(rp, 32)), dim3(256), 0, s, X, XT, nullptr, nullptr, rows, Kr, rp);
                 if (splits == 1) {
                     EpiStoreF32 e{Gp(w), Kr, nullptr, Kr};
@@ -365,15 +418,12 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
                     GEMM_TRY(launch_gemm_splitk<bf16_t>(s, dYT, rp, XT, rp, Nc, Kr, rp, splits, WS(oSplit)));
                 }
             } else {
-                hipLaunchKernelGGL(k_rows_bf16, dim3(ceil_div(Nc, 256), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYR, fuse_bias ? WS(oPart) : nullptr, rows, Nc, rp);
+                hipLaunchKernelGGL(k_rows_bf16, dim3(ceil_div(Nc, 256), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYR, bpart, rows, Nc, rp);
                 GEMM_TRY(launch_gemm_tn(s, dYR, Nc, XR, Kr, Nc, Kr, rp, splits, splits == 1 ? Gp(w) : WS(oSplit)));
             }
             if (splits > 1) hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 64)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
-            if (fuse_bias) {
-                const int chunks = ceil_div(rows, 32);
-                if (Nc % 4 == 0 && chunks > 32) hipLaunchKernelGGL(k_colsum_final4, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), Gp(b), chunks, Nc, 0);
-                else hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc, 64)), dim3(256), 0, s, WS(oPart), Gp(b), chunks, Nc, 0);
-            } else if (!b.empty()) colsum(dY, nullptr, rows, Nc, Gp(b), 0);
+            if (fuse_bias) defer_final(bpart, Nc, ceil_div(rows, 32), Nc, Gp(b));
+            else if (!b.empty()) colsum_grad(dY, rows, Nc, Gp(b));
             if (dX) {
                 EpiStoreF32 e{dX, Kr, nullptr, Kr};
                 GEMM_TRY(launch_gemm<bf16_t>(s, dYR, Nc, WT, Nc, rows, Kr, Nc, e));
@@ -393,7 +443,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             }
             hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(Nc * Kr, 64)), dim3(256), 0, s, WS(oSplit), Gp(w), splits, Nc * Kr, 0);
         }
-        if (!b.empty()) colsum(dY, nullptr, rows, Nc, Gp(b), 0);
+        if (!b.empty()) colsum_grad(dY, rows, Nc, Gp(b));
         if (dX) {
             const int np = round_up(Nc, 4);
             const float *dYp = dY;
@@ -411,8 +461,10 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         hipLaunchKernelGGL(k_ln_bwd, dim3(ceil_div(M, 4)), dim3(256), 0, s, dy, x, mu, rs, Pp(g), dx, WS(oDwide2), M, D, accumulate);
         if (D % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)Gp(g) & 15) == 0 && ((uintptr_t)Gp(b) & 15) == 0) {      // d gamma and d beta in one pair of launches
             const int rows = colsum_chunk_rows(M), chunks = ceil_div(M, rows);
-            hipLaunchKernelGGL(k_colsum_partial4_2, dim3(ceil_div(2 * D, 256), chunks), dim3(256), 0, s, WS(oDwide2), dy, WS(oPart), M, D, rows);
-            hipLaunchKernelGGL(k_colsum_final_2, dim3(ceil_div(2 * D, 64)), dim3(256), 0, s, WS(oPart), Gp(g), Gp(b), chunks, D);
+            float *lp = part_alloc((size_t)chunks * 2 * D);
+            hipLaunchKernelGGL(k_colsum_partial4_2, dim3(ceil_div(2 * D, 256), chunks), dim3(256), 0, s, WS(oDwide2), dy, lp ? lp : WS(oPart), M, D, rows);
+            if (lp) { defer_final(lp, 2 * D, chunks, D, Gp(g)); defer_final(lp + D, 2 * D, chunks, D, Gp(b)); }
+            else hipLaunchKernelGGL(k_colsum_final_2, dim3(ceil_div(2 * D, 64)), dim3(256), 0, s, WS(oPart), Gp(g), Gp(b), chunks, D);
             return;
         }
         colsum(WS(oDwide2), nullptr, M, D, Gp(g), 0);
@@ -649,8 +701,8 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             }
             (void)hipMemsetAsync(WS(oDP), 0, (size_t)Rp * D * 4, s);
             hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(R * D, 64)), dim3(256), 0, s, WS(oLinePart), WS(oDP), N, R * D, 0);
-            colsum(du_part, nullptr, M, D, Gp(key(l, "1.module.attention.u_bias")), 0);
-            colsum(dvb_part, nullptr, M, D, Gp(key(l, "1.module.attention.v_bias")), 0);
+            colsum_grad(du_part, M, D, Gp(key(l, "1.module.attention.u_bias")));
+            colsum_grad(dvb_part, M, D, Gp(key(l, "1.module.attention.v_bias")));
             hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, du_part, dvb_part, 1.0f, MD);                 // d q
             // pos_proj weight: P = PE Wpos^T  ->  d Wpos = dP^T PE
             if ((rc = lin_bwd(WS(oDP), t->pe, key(l, "1.module.attention.pos_proj.linear.weight"), "", R, D, D, nullptr))) return rc;
@@ -692,6 +744,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         hipLaunchKernelGGL(k_conv_w_final, dim3(ceil_div(C * 10, 64)), dim3(256), 0, s, WS(oPart), chunks, C, Gp("encoder.conv_subsample.conv.0.weight"),
                            Gp("encoder.conv_subsample.conv.0.bias"));
     }
+    flush_finals();
     LAUNCH_CHECK();
     return COCR_OK;
 }

@@ -166,6 +166,32 @@ __global__ __launch_bounds__(256) static void k_colsum_final_2(const float *__re
         *reinterpret_cast<f32x4 *>(n2 < N ? out1 + n2 : out2 + (n2 - N)) = tot;
     }
 }
+// Round 4: the finals of a step's gradient column sums (bias gradients, LayerNorm d gamma / d beta) as ONE launch at the end of the backward
+// pass instead of one 4-workgroup launch each (330 of them, 7.6 us apiece: latency, not work).  A job = partial sums part[chunk * stride + n]
+// of `chunks` chunks for N columns (N % 4 == 0) -> out[n]; workgroup b of the launch serves job j with first_block[j] <= b < first_block[j + 1],
+// 64 columns each, 16 chunk groups added in a fixed order (bit-reproducible steps).
+#define COCR_MAX_COLSUM_JOBS 2048
+struct ColsumJob { const float *part; float *out; int stride, chunks, N, first_block; };
+__global__ __launch_bounds__(256) static void k_colsum_final_jobs(const ColsumJob *__restrict__ jobs, int njobs) {
+    __shared__ f32x4 red4[16][16];
+    int lo = 0, hi = njobs - 1;                              // the last job whose first block is <= this block (uniform)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ColsumJob j = jobs[lo];
+    const int cq = threadIdx.x & 15, kg = threadIdx.x >> 4, n = ((int)blockIdx.x - j.first_block) * 64 + 4 * cq;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < j.N) for (int k = kg; k < j.chunks; k += 16) s += *reinterpret_cast<const f32x4 *>(j.part + (size_t)k * j.stride + n);
+    red4[kg][cq] = s;
+    __syncthreads();
+    if (kg == 0 && n < j.N) {
+        f32x4 tot = red4[0][cq];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tot += red4[k][cq];
+        *reinterpret_cast<f32x4 *>(j.out + n) = tot;
+    }
+}
 // out[n] (+)= sum over `chunks` of part[k][n]: the same 64 x 4 arrangement over the chunks
 __global__ __launch_bounds__(256) static void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int chunks, int N, int accumulate) {
     __shared__ float red[4][64];
