@@ -529,11 +529,9 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         ln_fwd(xin, key(l, (pre + "0.weight").c_str()), key(l, (pre + "0.bias").c_str()), WS(oxn), WS(omu), WS(ors));
         int r;
         if ((r = lin_fwd(WS(oxn), key(l, (pre + "1.linear.weight").c_str()), key(l, (pre + "1.linear.bias").c_str()), M, ff, D, WS(oh)))) return r;
-        hipLaunchKernelGGL(k_silu_fwd, grid1((size_t)M * ff), dim3(256), 0, s, WS(oh), WS(oa), (size_t)M * ff);
-        dropout(WS(oa), (size_t)M * ff, p_ff, 16 * l + 2 + 8 * which);
+        hipLaunchKernelGGL(k_silu_fwd_drop, grid1((size_t)M * ff), dim3(256), 0, s, WS(oh), WS(oa), (size_t)M * ff, p_ff, (unsigned long long)seed, (unsigned)(16 * l + 2 + 8 * which));
         if ((r = lin_fwd(WS(oa), key(l, (pre + "4.linear.weight").c_str()), key(l, (pre + "4.linear.bias").c_str()), M, D, ff, WS(oDa)))) return r;
-        dropout(WS(oDa), MD, p_ff, 16 * l + 3 + 8 * which);
-        hipLaunchKernelGGL(k_add3, grid1(MD), dim3(256), 0, s, xout, xin, WS(oDa), ffr, MD);
+        hipLaunchKernelGGL(k_add3_drop, grid1(MD), dim3(256), 0, s, xout, xin, WS(oDa), ffr, MD, p_ff, (unsigned long long)seed, (unsigned)(16 * l + 3 + 8 * which));
         return COCR_OK;
     };
     for (int l = 0; l < L; ++l) {
@@ -562,8 +560,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
                                p_at, (unsigned long long)seed, (unsigned)(16 * l + 4));
         }
         if ((rc = lin_fwd(WS(a.ctx), key(l, "1.module.attention.out_proj.linear.weight"), key(l, "1.module.attention.out_proj.linear.bias"), M, D, D, WS(oDa)))) return rc;
-        dropout(WS(oDa), MD, p_at, 16 * l + 5);
-        hipLaunchKernelGGL(k_add3, grid1(MD), dim3(256), 0, s, WS(a.x2), WS(a.x1), WS(oDa), 1.0f, MD);
+        hipLaunchKernelGGL(k_add3_drop, grid1(MD), dim3(256), 0, s, WS(a.x2), WS(a.x1), WS(oDa), 1.0f, MD, p_at, (unsigned long long)seed, (unsigned)(16 * l + 5));
         // conv module
         ln_fwd(WS(a.x2), key(l, "2.module.sequential.0.weight"), key(l, "2.module.sequential.0.bias"), WS(a.xn3), WS(a.mu3), WS(a.rs3));
         if ((rc = lin_fwd(WS(a.xn3), key(l, "2.module.sequential.2.conv.weight"), key(l, "2.module.sequential.2.conv.bias"), M, 2 * D, D, WS(a.ga)))) return rc;
@@ -579,8 +576,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
                            Pp(key(l, "2.module.sequential.5.bias")), WS(a.xhat), WS(a.bny), M, D);
         hipLaunchKernelGGL(k_silu_fwd, grid1(MD), dim3(256), 0, s, WS(a.bny), WS(a.sact), MD);
         if ((rc = lin_fwd(WS(a.sact), key(l, "2.module.sequential.7.conv.weight"), key(l, "2.module.sequential.7.conv.bias"), M, D, D, WS(oDa)))) return rc;
-        dropout(WS(oDa), MD, p_cv, 16 * l + 6);
-        hipLaunchKernelGGL(k_add3, grid1(MD), dim3(256), 0, s, WS(a.x3), WS(a.x2), WS(oDa), 1.0f, MD);
+        hipLaunchKernelGGL(k_add3_drop, grid1(MD), dim3(256), 0, s, WS(a.x3), WS(a.x2), WS(oDa), 1.0f, MD, p_cv, (unsigned long long)seed, (unsigned)(16 * l + 6));
         if ((rc = ffn_fwd(l, 1, WS(a.x3), a.xn4, a.mu4, a.rs4, a.h4, a.a4, WS(a.x4)))) return rc;
         float *xnext = l + 1 < L ? WS(lay[l + 1].x_in) : WS(oXout);
         ln_fwd(WS(a.x4), key(l, "4.weight"), key(l, "4.bias"), xnext, WS(a.mu5), WS(a.rs5));
@@ -605,13 +601,10 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         // x_out = x_in + ffr drop(W2 drop(silu(W1 LN(x_in) + b1)) + b2): dxio holds d x_out on entry, d x_in on exit
         const std::string pre = std::string(which == 0 ? "0" : "3") + ".module.sequential.";
         float *dob = WS(oDa);
-        (void)hipMemsetAsync(dob, 0, MD * 4, s);
-        hipLaunchKernelGGL(k_axpy, grid1(MD), dim3(256), 0, s, dob, dxio, ffr, MD);
-        dropout(dob, MD, p_ff, 16 * l + 3 + 8 * which);
+        hipLaunchKernelGGL(k_scale_drop, grid1(MD), dim3(256), 0, s, dob, dxio, ffr, MD, p_ff, (unsigned long long)seed, (unsigned)(16 * l + 3 + 8 * which));
         int r;
         if ((r = lin_bwd(dob, WS(oa), key(l, (pre + "4.linear.weight").c_str()), key(l, (pre + "4.linear.bias").c_str()), M, D, ff, WS(oDwide)))) return r;
-        dropout(WS(oDwide), (size_t)M * ff, p_ff, 16 * l + 2 + 8 * which);
-        hipLaunchKernelGGL(k_silu_bwd, grid1((size_t)M * ff), dim3(256), 0, s, WS(oh), WS(oDwide), (size_t)M * ff);
+        hipLaunchKernelGGL(k_silu_bwd_drop, grid1((size_t)M * ff), dim3(256), 0, s, WS(oh), WS(oDwide), (size_t)M * ff, p_ff, (unsigned long long)seed, (unsigned)(16 * l + 2 + 8 * which));
         if ((r = lin_bwd(WS(oDwide), WS(oxn), key(l, (pre + "1.linear.weight").c_str()), key(l, (pre + "1.linear.bias").c_str()), M, ff, D, WS(oDc)))) return r;
         ln_bwd(WS(oDc), xin, WS(omu), WS(ors), key(l, (pre + "0.weight").c_str()), key(l, (pre + "0.bias").c_str()), dxio, 1);
         return COCR_OK;
@@ -625,8 +618,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         // conv module: x3 = x2 + drop(pw2(silu(bn(dw(glu(pw1(LN(x2))))))))
         {
             float *dob = WS(oDa);
-            copy(dob, dx, MD);
-            dropout(dob, MD, p_cv, 16 * l + 6);
+            hipLaunchKernelGGL(k_scale_drop, grid1(MD), dim3(256), 0, s, dob, dx, 1.0f, MD, p_cv, (unsigned long long)seed, (unsigned)(16 * l + 6));
             if ((rc = lin_bwd(dob, WS(a.sact), key(l, "2.module.sequential.7.conv.weight"), key(l, "2.module.sequential.7.conv.bias"), M, D, D, WS(oDc)))) return rc;
             hipLaunchKernelGGL(k_silu_bwd, grid1(MD), dim3(256), 0, s, WS(a.bny), WS(oDc), MD);               // d bn_y
             colsum(WS(oDc), nullptr, M, D, WS(oVec), 0);                                                      // sum dy   = d beta
@@ -658,8 +650,7 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         // MHSA: x2 = x1 + drop(out_proj(attention(LN(x1))))
         {
             float *dob = WS(oDa);
-            copy(dob, dx, MD);
-            dropout(dob, MD, p_at, 16 * l + 5);
+            hipLaunchKernelGGL(k_scale_drop, grid1(MD), dim3(256), 0, s, dob, dx, 1.0f, MD, p_at, (unsigned long long)seed, (unsigned)(16 * l + 5));
             if ((rc = lin_bwd(dob, WS(a.ctx), key(l, "1.module.attention.out_proj.linear.weight"), key(l, "1.module.attention.out_proj.linear.bias"), M, D, D, WS(oDc)))) return rc;   // d ctx
             float *du_part = WS(oDwide), *dvb_part = WS(oDwide) + MD;
             const float *ub = Pp(key(l, "1.module.attention.u_bias")), *vbp = Pp(key(l, "1.module.attention.v_bias"));

@@ -25,6 +25,21 @@ __global__ static void k_dropout(float *x, size_t n, float p, unsigned long long
         x[i] = drop_keep(seed, site, i, p) ? x[i] * sc : 0.f;
 }
 
+// Round 4: the dropout folded into the elementwise kernel beside it (the same values: the same multiply by 1 / (1 - p) at the same place in the
+// chain; p = 0 leaves the value alone) -- a training step had 146 dropout launches, 72 of them behind a copy or a scaled copy.
+__device__ __forceinline__ float drop_apply(float v, unsigned long long seed, unsigned site, unsigned long long idx, float p, float sc) {
+    return p > 0.f ? (drop_keep(seed, site, idx, p) ? v * sc : 0.f) : v;
+}
+// y = a + alpha drop(b)          (a sublayer's residual add)
+__global__ static void k_add3_drop(float *y, const float *a, const float *b, float alpha, size_t n, float p, unsigned long long seed, unsigned site) {
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaf(alpha, drop_apply(b[i], seed, site, i, p, sc), a[i]);
+}
+// out = drop(alpha in)           (the gradient entering a sublayer's last dropout: zero + alpha x, dropped)
+__global__ static void k_scale_drop(float *out, const float *in, float alpha, size_t n, float p, unsigned long long seed, unsigned site) {
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = drop_apply(fmaf(alpha, in[i], 0.f), seed, site, i, p, sc);
+}
 // ---- small elementwise helpers ------------------------------------------------------------------------------------------------------
 __global__ static void k_axpy(float *y, const float *x, float alpha, size_t n) {          // y += alpha x
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaf(alpha, x[i], y[i]);
@@ -260,6 +275,18 @@ __global__ static void k_ln_bwd(const float *__restrict__ dy, const float *__res
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 __global__ static void k_silu_fwd(const float *__restrict__ h, float *__restrict__ a, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = h[i] * sigm(h[i]);
+}
+// a = drop(silu(h)); d <- drop(d) * silu'(h): the feed-forward module's hidden dropout folded into its activation, forward and backward
+__global__ static void k_silu_fwd_drop(const float *__restrict__ h, float *__restrict__ a, size_t n, float p, unsigned long long seed, unsigned site) {
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = drop_apply(h[i] * sigm(h[i]), seed, site, i, p, sc);
+}
+__global__ static void k_silu_bwd_drop(const float *__restrict__ h, float *__restrict__ d, size_t n, float p, unsigned long long seed, unsigned site) {
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = sigm(h[i]);
+        d[i] = drop_apply(d[i], seed, site, i, p, sc) * (s * fmaf(h[i], 1.0f - s, 1.0f));
+    }
 }
 __global__ static void k_silu_bwd(const float *__restrict__ h, float *__restrict__ d, size_t n) {      // d <- d * silu'(h)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
