@@ -568,13 +568,18 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         if (K == 31) hipLaunchKernelGGL((k_dw1d_rows<false, 31>), dim3(ceil_div(D, 256), ceil_div(T, COCR_DW_TC), N), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K);
         else if (K <= 32) hipLaunchKernelGGL((k_dw1d_rows<false, 0>), dim3(ceil_div(D, 256), ceil_div(T, COCR_DW_TC), N), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K);
         else hipLaunchKernelGGL(k_dw1d_fwd_flat, grid1(MD), dim3(256), 0, s, WS(a.g), Pp(key(l, "2.module.sequential.4.conv.weight")), WS(a.dwo), N, T, D, K, 0);
-        colsum(WS(a.dwo), nullptr, M, D, WS(oVec), 0);
-        colsum(WS(a.dwo), WS(a.dwo), M, D, WS(oVec) + D, 0);
+        if (D % 4 == 0) {                                  // sum x and sum x^2 in one pass
+            const int rows = colsum_chunk_rows(M), chunks = ceil_div(M, rows);
+            hipLaunchKernelGGL(k_colsum_partial4_sq, dim3(ceil_div(2 * D, 256), chunks), dim3(256), 0, s, WS(a.dwo), WS(oPart), M, D, rows);
+            hipLaunchKernelGGL(k_colsum_final_2, dim3(ceil_div(2 * D, 64)), dim3(256), 0, s, WS(oPart), WS(oVec), WS(oVec) + D, chunks, D);
+        } else {
+            colsum(WS(a.dwo), nullptr, M, D, WS(oVec), 0);
+            colsum(WS(a.dwo), WS(a.dwo), M, D, WS(oVec) + D, 0);
+        }
         hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(D, 256)), dim3(256), 0, s, WS(oVec), WS(oVec) + D, M, D, WS(a.bnm), WS(a.bnr),
                            Pp(key(l, "2.module.sequential.5.running_mean")), Pp(key(l, "2.module.sequential.5.running_var")), 0.1f);
-        hipLaunchKernelGGL(k_bn_apply, grid1(MD), dim3(256), 0, s, WS(a.dwo), WS(a.bnm), WS(a.bnr), Pp(key(l, "2.module.sequential.5.weight")),
-                           Pp(key(l, "2.module.sequential.5.bias")), WS(a.xhat), WS(a.bny), M, D);
-        hipLaunchKernelGGL(k_silu_fwd, grid1(MD), dim3(256), 0, s, WS(a.bny), WS(a.sact), MD);
+        hipLaunchKernelGGL(k_bn_apply_silu, grid1(MD), dim3(256), 0, s, WS(a.dwo), WS(a.bnm), WS(a.bnr), Pp(key(l, "2.module.sequential.5.weight")),
+                           Pp(key(l, "2.module.sequential.5.bias")), WS(a.xhat), WS(a.bny), WS(a.sact), M, D);
         if ((rc = lin_fwd(WS(a.sact), key(l, "2.module.sequential.7.conv.weight"), key(l, "2.module.sequential.7.conv.bias"), M, D, D, WS(oDa)))) return rc;
         hipLaunchKernelGGL(k_add3_drop, grid1(MD), dim3(256), 0, s, WS(a.x3), WS(a.x2), WS(oDa), 1.0f, MD, p_cv, (unsigned long long)seed, (unsigned)(16 * l + 6));
         if ((rc = ffn_fwd(l, 1, WS(a.x3), a.xn4, a.mu4, a.rs4, a.h4, a.a4, WS(a.x4)))) return rc;

@@ -167,6 +167,18 @@ __global__ __launch_bounds__(256) static void k_colsum_partial4_2(const float *_
     __syncthreads();
     if (rg == 0 && n2 < 2 * N) *reinterpret_cast<f32x4 *>(part + (size_t)chunk * 2 * N + n2) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
 }
+// part[chunk][2 N] = column sums of a | of a .* a over the chunk's rows (BatchNorm's batch statistics in one pass; N % 4 == 0)
+__global__ __launch_bounds__(256) static void k_colsum_partial4_sq(const float *__restrict__ a, float *__restrict__ part, int M, int N, int rows) {
+    __shared__ f32x4 red4[4][64];
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6, n2 = blockIdx.x * 256 + 4 * cq, chunk = blockIdx.y;
+    const int r0 = chunk * rows, r1 = min(M, r0 + rows);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n2 < N) { for (int r = r0 + rg; r < r1; r += 4) s += *reinterpret_cast<const f32x4 *>(a + (size_t)r * N + n2); }
+    else if (n2 < 2 * N) { for (int r = r0 + rg; r < r1; r += 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(a + (size_t)r * N + n2 - N); s = __builtin_elementwise_fma(v, v, s); } }
+    red4[rg][cq] = s;
+    __syncthreads();
+    if (rg == 0 && n2 < 2 * N) *reinterpret_cast<f32x4 *>(part + (size_t)chunk * 2 * N + n2) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
+}
 __global__ __launch_bounds__(256) static void k_colsum_final_2(const float *__restrict__ part, float *__restrict__ out1, float *__restrict__ out2, int chunks, int N) {
     __shared__ f32x4 red4[16][16];
     const int cq = threadIdx.x & 15, kg = threadIdx.x >> 4, n2 = blockIdx.x * 64 + 4 * cq;
@@ -675,6 +687,18 @@ __global__ static void k_bn_apply(const float *__restrict__ x, const float *__re
         const float xh = (x[i] - mean[c]) * rstd[c];
         xhat[i] = xh;
         y[i] = fmaf(xh, g[c], b[c]);
+    }
+}
+// the same with the SiLU behind it (convolution.py:141-142): xhat, y = BatchNorm output, a = silu(y) in one pass
+__global__ static void k_bn_apply_silu(const float *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ g,
+                                       const float *__restrict__ b, float *__restrict__ xhat, float *__restrict__ y, float *__restrict__ a, int M, int D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * D; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const float xh = (x[i] - mean[c]) * rstd[c];
+        xhat[i] = xh;
+        const float v = fmaf(xh, g[c], b[c]);
+        y[i] = v;
+        a[i] = v * sigm(v);
     }
 }
 // dx = g rstd / M (M dy - sum dy - xhat sum(dy xhat))
