@@ -372,6 +372,9 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
         hipLaunchKernelGGL(k_colsum_partial4, dim3(ceil_div(Nc, 256), chunks), dim3(256), 0, s, a, (const float *)nullptr, gp, Mr, Nc, rows);
         defer_final(gp, Nc, chunks, Nc, out);
     };
+    const float *last_x = nullptr;                 // 'medium': the input of the last lin_fwd and where its bf16 copy lies
+    int last_rows = 0, last_k = 0, last_rp = 0;
+    size_t last_xo = 0;
     // Y (rows, Nc) = X (rows, Kr) W(Nc, Kr)^T + b
     auto lin_fwd = [&](const float *X, const std::string &w, const std::string &b, int rows, int Nc, int Kr, float *Y) -> int {
         if (t->matmul_bf16 && t->Wb && Nc % 8 == 0 && Kr % 8 == 0) {
@@ -381,12 +384,20 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Kr, 32), ceil_div(Nc, 32)), dim3(256), 0, s, Pp(w), WT, Wb, nullptr, Nc, Kr, Nc);
             // the input's bf16 copy is kept for the backward (K-major operand of dW = dY^T X: rows zero-padded to that product's depth)
             const int rp = round_up(rows, 64 * wg_splits(Nc, Kr));
-            const size_t xo = t->Xb_used, xbytes = ((size_t)rp * Kr * 2 + 255) / 256 * 256;
-            if (xo + xbytes > t->Xb_bytes) return fail(COCR_ESTATE, "training: bf16 activation arena too small (%zu + %zu > %zu)", xo, xbytes, t->Xb_bytes);
-            t->Xb_used += xbytes;
-            t->Xb_off[w] = xo;
-            bf16_t *Ab = reinterpret_cast<bf16_t *>(t->Xb + xo);
-            hipLaunchKernelGGL(k_rows_bf16, dim3(ceil_div(Kr, 256), ceil_div(rp, 32)), dim3(256), 0, s, X, Ab, nullptr, rows, Kr, rp);
+            bf16_t *Ab;
+            if (X == last_x && rows == last_rows && Kr == last_k && rp <= last_rp) {
+                // the same input as the Linear just before (the query / key / value projections read one LayerNorm output): one copy serves both
+                t->Xb_off[w] = last_xo;
+                Ab = reinterpret_cast<bf16_t *>(t->Xb + last_xo);
+            } else {
+                const size_t xo = t->Xb_used, xbytes = ((size_t)rp * Kr * 2 + 255) / 256 * 256;
+                if (xo + xbytes > t->Xb_bytes) return fail(COCR_ESTATE, "training: bf16 activation arena too small (%zu + %zu > %zu)", xo, xbytes, t->Xb_bytes);
+                t->Xb_used += xbytes;
+                t->Xb_off[w] = xo;
+                Ab = reinterpret_cast<bf16_t *>(t->Xb + xo);
+                hipLaunchKernelGGL(k_rows_bf16, dim3(ceil_div(Kr, 256), ceil_div(rp, 32)), dim3(256), 0, s, X, Ab, nullptr, rows, Kr, rp);
+                last_x = X; last_rows = rows; last_k = Kr; last_rp = rp; last_xo = xo;
+            }
             EpiStoreF32 e{Y, Nc, b.empty() ? nullptr : Pp(b), Nc};
             GEMM_TRY(launch_gemm<bf16_t>(s, Ab, Kr, Wb, Kr, rows, Nc, Kr, e));
             return COCR_OK;
@@ -626,12 +637,20 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             hipLaunchKernelGGL(k_scale_drop, grid1(MD), dim3(256), 0, s, dob, dx, 1.0f, MD, p_cv, (unsigned long long)seed, (unsigned)(16 * l + 6));
             if ((rc = lin_bwd(dob, WS(a.sact), key(l, "2.module.sequential.7.conv.weight"), key(l, "2.module.sequential.7.conv.bias"), M, D, D, WS(oDc)))) return rc;
             hipLaunchKernelGGL(k_silu_bwd, grid1(MD), dim3(256), 0, s, WS(a.bny), WS(oDc), MD);               // d bn_y
-            colsum(WS(oDc), nullptr, M, D, WS(oVec), 0);                                                      // sum dy   = d beta
-            colsum(WS(oDc), WS(a.xhat), M, D, WS(oVec) + D, 0);                                               // sum dy xhat = d gamma
-            copy(Gp(key(l, "2.module.sequential.5.bias")), WS(oVec), D);
-            copy(Gp(key(l, "2.module.sequential.5.weight")), WS(oVec) + D, D);
-            hipLaunchKernelGGL(k_bn_bwd, grid1(MD), dim3(256), 0, s, WS(oDc), WS(a.xhat), Pp(key(l, "2.module.sequential.5.weight")), WS(a.bnr), WS(oVec),
-                               WS(oVec) + D, WS(oDe), M, D);                                                  // d dwo
+            float *gbeta = Gp(key(l, "2.module.sequential.5.bias")), *ggamma = Gp(key(l, "2.module.sequential.5.weight"));
+            if (D % 4 == 0 && ((uintptr_t)gbeta & 15) == 0 && ((uintptr_t)ggamma & 15) == 0) {
+                // sum dy (= d beta) and sum dy xhat (= d gamma) in one pass, straight into the gradient vector; the input gradient reads them there
+                const int rows = colsum_chunk_rows(M), chunks = ceil_div(M, rows);
+                hipLaunchKernelGGL(k_colsum_partial4_ab, dim3(ceil_div(2 * D, 256), chunks), dim3(256), 0, s, WS(oDc), WS(a.xhat), WS(oPart), M, D, rows);
+                hipLaunchKernelGGL(k_colsum_final_2, dim3(ceil_div(2 * D, 64)), dim3(256), 0, s, WS(oPart), gbeta, ggamma, chunks, D);
+            } else {
+                colsum(WS(oDc), nullptr, M, D, WS(oVec), 0);                                                      // sum dy   = d beta
+                colsum(WS(oDc), WS(a.xhat), M, D, WS(oVec) + D, 0);                                               // sum dy xhat = d gamma
+                copy(gbeta, WS(oVec), D);
+                copy(ggamma, WS(oVec) + D, D);
+            }
+            hipLaunchKernelGGL(k_bn_bwd, grid1(MD), dim3(256), 0, s, WS(oDc), WS(a.xhat), Pp(key(l, "2.module.sequential.5.weight")), WS(a.bnr), gbeta,
+                               ggamma, WS(oDe), M, D);                                                        // d dwo
             if (K <= 32) {
                 const int nch = ceil_div(T, COCR_DW_WC);
                 const dim3 gw(ceil_div(D, 256), nch, N), gr(ceil_div(D, 256), ceil_div(T, COCR_DW_TC), N);

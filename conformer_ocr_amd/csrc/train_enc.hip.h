@@ -179,6 +179,21 @@ __global__ __launch_bounds__(256) static void k_colsum_partial4_sq(const float *
     __syncthreads();
     if (rg == 0 && n2 < 2 * N) *reinterpret_cast<f32x4 *>(part + (size_t)chunk * 2 * N + n2) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
 }
+// part[chunk][2 N] = column sums of a | of a .* b (BatchNorm backward: sum dy = d beta, sum dy xhat = d gamma; N % 4 == 0)
+__global__ __launch_bounds__(256) static void k_colsum_partial4_ab(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ part, int M, int N, int rows) {
+    __shared__ f32x4 red4[4][64];
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6, n2 = blockIdx.x * 256 + 4 * cq, chunk = blockIdx.y;
+    const int r0 = chunk * rows, r1 = min(M, r0 + rows);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n2 < N) { for (int r = r0 + rg; r < r1; r += 4) s += *reinterpret_cast<const f32x4 *>(a + (size_t)r * N + n2); }
+    else if (n2 < 2 * N) {
+        for (int r = r0 + rg; r < r1; r += 4)
+            s = __builtin_elementwise_fma(*reinterpret_cast<const f32x4 *>(a + (size_t)r * N + n2 - N), *reinterpret_cast<const f32x4 *>(b + (size_t)r * N + n2 - N), s);
+    }
+    red4[rg][cq] = s;
+    __syncthreads();
+    if (rg == 0 && n2 < 2 * N) *reinterpret_cast<f32x4 *>(part + (size_t)chunk * 2 * N + n2) = ((red4[0][cq] + red4[1][cq]) + red4[2][cq]) + red4[3][cq];
+}
 __global__ __launch_bounds__(256) static void k_colsum_final_2(const float *__restrict__ part, float *__restrict__ out1, float *__restrict__ out2, int chunks, int N) {
     __shared__ f32x4 red4[16][16];
     const int cq = threadIdx.x & 15, kg = threadIdx.x >> 4, n2 = blockIdx.x * 64 + 4 * cq;
