@@ -391,7 +391,16 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
                 Ab = reinterpret_cast<bf16_t *>(t->Xb + last_xo);
             } else {
                 const size_t xo = t->Xb_used, xbytes = ((size_t)rp * Kr * 2 + 255) / 256 * 256;
-                if (xo + xbytes > t->Xb_bytes) return fail(COCR_ESTATE, "training: bf16 activation arena too small (%zu + %zu > %zu)", xo, xbytes, t->Xb_bytes);
+                if (xo + xbytes > t->Xb_bytes) {
+                    // (the arena's size is an estimate over the model's Linears: a shape it did not foresee keeps no copy -- the backward
+                    // of this Linear then converts and transposes its operands itself, as before gemm_tn_kernel)
+                    t->Xb_off.erase(w);
+                    last_x = nullptr;
+                    const bf16_t *A1 = to_bf16(X, oBfA, (size_t)rows * Kr);
+                    EpiStoreF32 e1{Y, Nc, b.empty() ? nullptr : Pp(b), Nc};
+                    GEMM_TRY(launch_gemm<bf16_t>(s, A1, Kr, Wb, Kr, rows, Nc, Kr, e1));
+                    return COCR_OK;
+                }
                 t->Xb_used += xbytes;
                 t->Xb_off[w] = xo;
                 Ab = reinterpret_cast<bf16_t *>(t->Xb + xo);
@@ -413,11 +422,13 @@ extern "C" int cocr_train_step(cocr_model *m, const void *lines, int line_dtype,
             // weight-gradient product's depth, the bias gradient's partial sums on the way); X's copy is the forward's; the weight gradient
             // dW = dY^T X reads both K-major (gemm_tn_kernel: no transposed copies), the input gradient takes the forward's W^T.
             bf16_t *dYR = reinterpret_cast<bf16_t *>(WS(oTA));
-            const bf16_t *XR = reinterpret_cast<const bf16_t *>(t->Xb + t->Xb_off.at(w));
+            const auto xit = t->Xb_off.find(w);
+            const bool have_x = xit != t->Xb_off.end();          // (no copy kept: the forward's arena was full)
+            const bf16_t *XR = have_x ? reinterpret_cast<const bf16_t *>(t->Xb + xit->second) : nullptr;
             const bf16_t *WT = reinterpret_cast<const bf16_t *>(t->WTb + t->idx.at(w).off * 4);          // written by lin_fwd of this step
             float *bpart = (!b.empty() && colsum_chunk_rows(rows) == 32 && ((uintptr_t)Gp(b) & 15) == 0) ? part_alloc((size_t)ceil_div(rows, 32) * Nc) : nullptr;
             const bool fuse_bias = bpart != nullptr;
-            if (t->no_tn) {
+            if (t->no_tn || !have_x) {
                 // COCR_TRAIN_NO_TN=1 (A/B of the test): the weight-gradient product on transposed bf16 copies, as before gemm_tn_kernel existed
                 bf16_t *dYT = reinterpret_cast<bf16_t *>(t->ws + oBfA), *XT = reinterpret_cast<bf16_t *>(t->ws + oBfW);
                 hipLaunchKernelGGL(k_transpose_bf16, dim3(ceil_div(Nc, 32), ceil_div(rp, 32)), dim3(256), 0, s, dY, dYT, dX ? dYR : nullptr, bpart, rows, Nc, rp);
